@@ -1,0 +1,174 @@
+/*
+ * snappy_hip.h -- C ABI of libsnappy_hip.so, the MI355X (gfx950) drop-in for the
+ * UPMEM-DPU offload path of UBC-ECE-Sasha/PIM-compression's `dpu_snappy`.
+ *
+ * Two layers are exported:
+ *
+ *  1. The drop-in pair, with the exact shape of the reference's L2 entry points
+ *       snappy_compress_dpu    (reference snappy/snappy_compress.h:37,  snappy_compress.c:487)
+ *       snappy_decompress_dpu  (reference snappy/snappy_decompress.h:34, snappy_decompress.c:292)
+ *     They take the reference's own `struct host_buffer_context` /
+ *     `struct program_runtime` (reference snappy/dpu_snappy.h:37-55) and return its
+ *     `snappy_status` (dpu_snappy.h:21-25).  `main` in dpu_snappy.c:169-172 / :189-192
+ *     calls them where it called the *_dpu functions.
+ *
+ *  2. A resident API over device pointers (what the drop-in pair is built from, and what
+ *     bench.py / the tests drive): per-block compress into worst-case slots, scan+compact
+ *     into the framed stream, size-chain indexing, per-block decompress.  It replaces the
+ *     dpu_alloc / dpu_push_xfer / dpu_launch plumbing (snappy_compress.c:535-618,
+ *     snappy_decompress.c:351-439) with hipMalloc / hipMemcpy / kernel launches.
+ *
+ * Plain C: pointers and sizes only.  No CPU fallback exists behind any entry point: if no
+ * HIP device / code object is usable they fail with SNAPPY_HIP_ERR_* (resident API) or
+ * SNAPPY_INVALID_INPUT (drop-in pair, as the reference maps a failed dpu_launch,
+ * snappy_compress.c:618-623) and say why on stderr / via snappy_hip_last_error().
+ */
+#ifndef SNAPPY_HIP_H_
+#define SNAPPY_HIP_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- types shared with the reference (layout-identical; skipped when the
+ *      reference's own dpu_snappy.h was included first) ------------------- */
+#ifndef _DPU_SNAPPY_H_
+typedef enum {
+	SNAPPY_OK = 0,
+	SNAPPY_INVALID_INPUT,
+	SNAPPY_BUFFER_TOO_SMALL
+} snappy_status;                        /* dpu_snappy.h:21-25 */
+
+typedef struct host_buffer_context {
+	const char *file_name;
+	uint8_t *buffer;
+	uint8_t *curr;
+	unsigned long length;
+	unsigned long max;
+} host_buffer_context;                  /* dpu_snappy.h:37-44 */
+
+struct program_runtime {
+	double pre;
+	double d_alloc;
+	double load;
+	double copy_in;
+	double run;
+	double copy_out;
+	double d_free;
+};                                      /* dpu_snappy.h:47-55 */
+#endif
+
+/* ---- 1. drop-in pair ----------------------------------------------------- */
+
+/*
+ * Replaces snappy_compress_dpu (snappy_compress.c:487-714).
+ * Entry: input->buffer/curr at file start, input->length = n.  output->buffer may be NULL
+ * or any malloc'd block; it is realloc'd to the needed size (the reference's
+ * 32+n+n/6, snappy_compress.c:446-447, is too small for tiny block sizes).
+ * Exit: framed stream in output->buffer[0..output->length); caller writes the file.
+ * Fills every field of *runtime (pre is accumulated with +=, as snappy_compress.c:528).
+ * Uses SNAPPY_HIP_NUM_GPUS devices (env, default: all visible), contiguous block ranges
+ * per device (snappy_compress.c:494-520), host-side concat of per-device outputs.
+ */
+snappy_status snappy_compress_gpu(struct host_buffer_context *input, struct host_buffer_context *output,
+                                  uint32_t block_size, struct program_runtime *runtime);
+
+/*
+ * Replaces snappy_decompress_dpu (snappy_decompress.c:292-493).
+ * Entry (as left by setup_decompression, snappy_decompress.c:187-215): input->curr just
+ * past the first varint; output->buffer malloc'd, output->length = uncompressed length.
+ * Reads the block-size varint itself (snappy_decompress.c:300), walks the u32 size chain on
+ * the host (:317-340), decodes block i into output->buffer + i*block_size (:330).
+ * Stricter than the host decoder: a block that overruns its compressed size, its output
+ * window, or references bytes before its own start yields SNAPPY_INVALID_INPUT.
+ */
+snappy_status snappy_decompress_gpu(struct host_buffer_context *input, struct host_buffer_context *output,
+                                    struct program_runtime *runtime);
+
+/* ---- 2. resident API ----------------------------------------------------- */
+
+#define SNAPPY_HIP_OK            0
+#define SNAPPY_HIP_ERR_NO_DEVICE 1   /* no usable HIP device / runtime */
+#define SNAPPY_HIP_ERR_ARG       2   /* bad argument (alignment, sizes, null) */
+#define SNAPPY_HIP_ERR_RUNTIME   3   /* a HIP call failed; see snappy_hip_last_error() */
+
+/* per-block status written by the decompress kernel */
+#define SNAPPY_HIP_BLOCK_OK        0u
+#define SNAPPY_HIP_BLOCK_INVALID   1u
+
+#define SNAPPY_HIP_MIN_BLOCK_SIZE  1u
+#define SNAPPY_HIP_MAX_BLOCK_SIZE  65535u   /* u16 hash table entries, snappy_compress.c:347 */
+
+/* Description of one framed stream for snappy_hip_index_streams. */
+typedef struct snappy_hip_stream_desc {
+	const uint8_t *stream;      /* device: start of the framed stream (its header)      */
+	uint64_t stream_len;        /* bytes                                                  */
+	uint64_t *block_offsets;    /* device out: offset of each block's u32 size prefix    */
+	uint32_t *result;           /* device out: [0]=status (SNAPPY_HIP_BLOCK_*), [1]=blocks walked */
+	uint32_t total_len;         /* uncompressed length from the header                    */
+	uint32_t block_size;        /* from the header                                        */
+	uint32_t header_len;        /* bytes of the two varints                               */
+	uint32_t num_blocks;        /* ceil(total_len / block_size)                           */
+} snappy_hip_stream_desc;
+
+int snappy_hip_device_count(void);
+int snappy_hip_set_device(int device);
+const char *snappy_hip_last_error(void);
+/* name of the code-object architecture this library was built for ("gfx950") */
+const char *snappy_hip_arch(void);
+
+/* Bytes reserved per block in the slot buffer: 16-byte multiple >= 4 + 32 + bs + bs/6
+ * (u32 prefix + snappy_max_compressed_length, snappy_compress.c:55-60). */
+uint32_t snappy_hip_slot_stride(uint32_t block_size);
+uint64_t snappy_hip_num_blocks(uint64_t input_len, uint32_t block_size);
+/* Upper bound of the framed stream for input_len bytes (header + all slots' payload). */
+uint64_t snappy_hip_stream_bound(uint64_t input_len, uint32_t block_size);
+/* Writes varint(total_len) varint(block_size) (snappy_compress.c:461-465) to a HOST buffer
+ * of >= 10 bytes; returns header length. */
+uint32_t snappy_hip_write_header(uint8_t *dst, uint32_t total_len, uint32_t block_size);
+/* Parses the two header varints from a HOST buffer (snappy_decompress.c:193-198, :220-225);
+ * returns header length, 0 if malformed. */
+uint32_t snappy_hip_parse_header(const uint8_t *src, uint64_t avail, uint32_t *total_len, uint32_t *block_size);
+
+/*
+ * K1: compress every block of d_in independently (semantics of compress_block,
+ * snappy_compress.c:284-413).  Block b's u32 size prefix + elements go to
+ * d_slots + b*slot_stride; d_block_bytes[b] = 4 + compressed size.
+ * d_in must be 16-byte aligned.  `stream` is a hipStream_t (NULL = default stream).
+ */
+int snappy_hip_compress_blocks(const uint8_t *d_in, uint64_t input_len, uint32_t block_size,
+                               uint8_t *d_slots, uint32_t slot_stride, uint32_t *d_block_bytes,
+                               void *stream);
+
+/*
+ * Exclusive scan of d_block_bytes + gather of the slots into the contiguous framed stream
+ * (header written too).  d_offsets: scratch/out, num_blocks+1 u64 (offset of each block in
+ * d_stream; [num_blocks] = stream length, also stored to *d_stream_len if non-NULL).
+ * This is the device-side form of the per-tasklet fwrite concat, snappy_compress.c:697-704.
+ */
+int snappy_hip_compact(const uint8_t *d_slots, uint32_t slot_stride, const uint32_t *d_block_bytes,
+                       uint64_t input_len, uint32_t block_size,
+                       uint8_t *d_stream, uint64_t *d_offsets, uint64_t *d_stream_len, void *stream);
+
+/*
+ * Walk the u32 size chains of `count` streams (one wavefront each), the device form of the
+ * host pre-scan snappy_decompress.c:317-340.  d_descs: device array of `count` descriptors.
+ */
+int snappy_hip_index_streams(const snappy_hip_stream_desc *d_descs, uint32_t count, void *stream);
+
+/*
+ * K2: decode every block (semantics of snappy_decompress.c:232-285 on well-formed streams,
+ * strict otherwise).  Block i is read at d_stream + d_block_offsets[i] and decoded to
+ * d_out + i*block_size; d_status[i] = SNAPPY_HIP_BLOCK_*.
+ */
+int snappy_hip_decompress_blocks(const uint8_t *d_stream, uint64_t stream_len, const uint64_t *d_block_offsets,
+                                 uint64_t total_len, uint32_t block_size,
+                                 uint8_t *d_out, uint32_t *d_status, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNAPPY_HIP_H_ */

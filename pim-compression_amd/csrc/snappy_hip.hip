@@ -1,0 +1,591 @@
+// snappy_hip.hip -- host side of libsnappy_hip.so: the C ABI declared in include/snappy_hip.h.
+//
+// Replaces the UPMEM offload plumbing of the reference (dpu_alloc / dpu_load / dpu_push_xfer /
+// dpu_launch / dpu_free in snappy/snappy_compress.c:487-714 and snappy/snappy_decompress.c:292-493)
+// with hipMalloc / hipMemcpy / kernel launches.  No CPU codec lives in this library: if HIP is
+// unusable every entry point fails and says so.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/snappy_hip.h"
+#include "snappy_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& what)
+{
+    g_last_error = what;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(SNAPPY_HIP_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+double now_seconds()
+{
+    struct timeval tv;
+    gettimeofday(&tv, nullptr);   // same clock as the reference's get_runtime (dpu_snappy.c:87-91)
+    return (double)tv.tv_sec + (double)tv.tv_usec / 1000000.0;
+}
+
+uint32_t put_varint32(uint8_t* dst, uint32_t v)   // snappy_compress.c:69-98
+{
+    uint32_t k = 0;
+    while (v >= 0x80) {
+        dst[k++] = (uint8_t)(v | 0x80);
+        v >>= 7;
+    }
+    dst[k++] = (uint8_t)v;
+    return k;
+}
+
+uint32_t get_varint32(const uint8_t* src, uint64_t avail, uint32_t* out)   // snappy_decompress.c:23-37
+{
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 5 && k < avail; ++k) {
+        const uint8_t c = src[k];
+        v |= (uint32_t)(c & 0x7f) << (7 * k);
+        if (!(c & 0x80)) {
+            *out = v;
+            return k + 1;
+        }
+    }
+    return 0;
+}
+
+uint32_t le32_host(const uint8_t* p)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+bool block_size_ok(uint32_t bs) { return bs >= SNAPPY_HIP_MIN_BLOCK_SIZE && bs <= SNAPPY_HIP_MAX_BLOCK_SIZE; }
+
+// Run fn(g) for g in [0, count) -- one host thread per device when count > 1 (pageable
+// hipMemcpy is synchronous per call, so threads are what overlaps the per-GPU transfers).
+int for_each_device(int count, const std::function<int(int)>& fn)
+{
+    if (count == 1) return fn(0);
+    std::vector<int> rc(count, 0);
+    std::vector<std::string> err(count);
+    std::vector<std::thread> th;
+    for (int g = 0; g < count; ++g)
+        th.emplace_back([&, g] {
+            rc[g] = fn(g);
+            if (rc[g]) err[g] = g_last_error;
+        });
+    for (auto& t : th) t.join();
+    for (int g = 0; g < count; ++g)
+        if (rc[g]) return fail(rc[g], "GPU " + std::to_string(g) + ": " + err[g]);
+    return 0;
+}
+
+int requested_gpus()
+{
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return 0;
+    const char* env = getenv("SNAPPY_HIP_NUM_GPUS");
+    if (env && *env) {
+        const int want = atoi(env);
+        if (want >= 1 && want < have) have = want;
+    }
+    return have;
+}
+
+}  // namespace
+
+// ===========================================================================
+// resident API
+// ===========================================================================
+extern "C" {
+
+int snappy_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        g_last_error = "hipGetDeviceCount failed: no usable HIP runtime/device";
+        return 0;
+    }
+    return n;
+}
+
+int snappy_hip_set_device(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return SNAPPY_HIP_OK;
+}
+
+const char* snappy_hip_last_error(void) { return g_last_error.c_str(); }
+
+const char* snappy_hip_arch(void) { return "gfx950"; }
+
+uint32_t snappy_hip_slot_stride(uint32_t block_size)
+{
+    const uint64_t need = 4ull + 32ull + block_size + block_size / 6;   // snappy_compress.c:55-60 + prefix
+    return (uint32_t)((need + 15) & ~15ull);
+}
+
+uint64_t snappy_hip_num_blocks(uint64_t input_len, uint32_t block_size)
+{
+    return block_size ? (input_len + block_size - 1) / block_size : 0;
+}
+
+uint64_t snappy_hip_stream_bound(uint64_t input_len, uint32_t block_size)
+{
+    return 10 + snappy_hip_num_blocks(input_len, block_size) * (uint64_t)snappy_hip_slot_stride(block_size);
+}
+
+uint32_t snappy_hip_write_header(uint8_t* dst, uint32_t total_len, uint32_t block_size)
+{
+    uint32_t k = put_varint32(dst, total_len);
+    k += put_varint32(dst + k, block_size);
+    return k;
+}
+
+uint32_t snappy_hip_parse_header(const uint8_t* src, uint64_t avail, uint32_t* total_len, uint32_t* block_size)
+{
+    const uint32_t a = get_varint32(src, avail, total_len);
+    if (!a) return 0;
+    const uint32_t b = get_varint32(src + a, avail - a, block_size);
+    if (!b) return 0;
+    return a + b;
+}
+
+int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t block_size, uint8_t* d_slots,
+                               uint32_t slot_stride, uint32_t* d_block_bytes, void* stream)
+{
+    if (!block_size_ok(block_size)) return fail(SNAPPY_HIP_ERR_ARG, "block_size must be 1..65535");
+    if (input_len > 0xffffffffull) return fail(SNAPPY_HIP_ERR_ARG, "container length must fit uint32 (snappy_compress.c:461)");
+    if (slot_stride < snappy_hip_slot_stride(block_size)) return fail(SNAPPY_HIP_ERR_ARG, "slot_stride too small");
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_slots & 15)) return fail(SNAPPY_HIP_ERR_ARG, "d_in and d_slots must be 16-byte aligned");
+    const uint64_t nb = snappy_hip_num_blocks(input_len, block_size);
+    if (nb == 0) return SNAPPY_HIP_OK;
+    if (!d_in || !d_slots || !d_block_bytes) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
+    hipLaunchKernelGGL(snappy_hip::compress_blocks_kernel, dim3((uint32_t)nb), dim3(64), 0, (hipStream_t)stream, d_in,
+                       input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb);
+    HIP_TRY(hipGetLastError());
+    return SNAPPY_HIP_OK;
+}
+
+int snappy_hip_compact(const uint8_t* d_slots, uint32_t slot_stride, const uint32_t* d_block_bytes, uint64_t input_len,
+                       uint32_t block_size, uint8_t* d_stream, uint64_t* d_offsets, uint64_t* d_stream_len, void* stream)
+{
+    if (!block_size_ok(block_size)) return fail(SNAPPY_HIP_ERR_ARG, "block_size must be 1..65535");
+    if (input_len > 0xffffffffull) return fail(SNAPPY_HIP_ERR_ARG, "container length must fit uint32");
+    if (!d_stream || !d_offsets) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
+    const uint32_t nb = (uint32_t)snappy_hip_num_blocks(input_len, block_size);
+    hipLaunchKernelGGL(snappy_hip::scan_block_bytes_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_block_bytes, nb,
+                       (uint32_t)input_len, block_size, d_stream, d_offsets, d_stream_len);
+    HIP_TRY(hipGetLastError());
+    if (nb) {
+        hipLaunchKernelGGL(snappy_hip::gather_slots_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, d_slots, slot_stride,
+                           d_block_bytes, d_offsets, d_stream, nb);
+        HIP_TRY(hipGetLastError());
+    }
+    return SNAPPY_HIP_OK;
+}
+
+int snappy_hip_index_streams(const snappy_hip_stream_desc* d_descs, uint32_t count, void* stream)
+{
+    static_assert(sizeof(snappy_hip_stream_desc) == sizeof(snappy_hip::StreamDesc), "descriptor layout");
+    if (count == 0) return SNAPPY_HIP_OK;
+    if (!d_descs) return fail(SNAPPY_HIP_ERR_ARG, "null descriptor array");
+    hipLaunchKernelGGL(snappy_hip::index_streams_kernel, dim3(count), dim3(64), 0, (hipStream_t)stream,
+                       reinterpret_cast<const snappy_hip::StreamDesc*>(d_descs), count);
+    HIP_TRY(hipGetLastError());
+    return SNAPPY_HIP_OK;
+}
+
+int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, const uint64_t* d_block_offsets,
+                                 uint64_t total_len, uint32_t block_size, uint8_t* d_out, uint32_t* d_status, void* stream)
+{
+    if (total_len == 0) return SNAPPY_HIP_OK;
+    if (!block_size_ok(block_size)) return fail(SNAPPY_HIP_ERR_ARG, "block_size must be 1..65535");
+    if (!d_stream || !d_block_offsets || !d_out || !d_status) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
+    const uint64_t nb = snappy_hip_num_blocks(total_len, block_size);
+    if (nb > 0x7fffffffull) return fail(SNAPPY_HIP_ERR_ARG, "too many blocks");
+    const uint32_t lds = (block_size + 15u) & ~15u;
+    hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel, dim3((uint32_t)nb), dim3(64), lds, (hipStream_t)stream, d_stream,
+                       stream_len, d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb);
+    HIP_TRY(hipGetLastError());
+    return SNAPPY_HIP_OK;
+}
+
+// ===========================================================================
+// drop-in pair (reference L2 signatures)
+// ===========================================================================
+
+namespace {
+
+struct CompressShard {
+    uint64_t first_block = 0, num_blocks = 0;
+    uint64_t in_off = 0, in_len = 0;
+    uint8_t *d_in = nullptr, *d_slots = nullptr, *d_stream = nullptr;
+    uint32_t* d_bytes = nullptr;
+    uint64_t *d_offsets = nullptr, *d_stream_len = nullptr;
+    uint64_t stream_len = 0;
+    uint32_t local_hdr = 0;
+    uint64_t out_off = 0;
+    float kernel_ms = 0.f;
+};
+
+struct DecompressShard {
+    uint64_t first_block = 0, num_blocks = 0;
+    uint64_t in_off = 0, in_len = 0;      // slice of the compressed stream (relative to input->buffer)
+    uint64_t out_off = 0, out_len = 0;
+    uint8_t *d_stream = nullptr, *d_out = nullptr;
+    uint64_t* d_boff = nullptr;
+    uint32_t* d_status = nullptr;
+    std::vector<uint64_t> rel_off;
+    float kernel_ms = 0.f;
+    bool bad = false;
+};
+
+snappy_status report(const char* where, int rc)
+{
+    fprintf(stderr, "snappy_hip: %s failed: %s\n", where, g_last_error.c_str());
+    (void)rc;
+    return SNAPPY_INVALID_INPUT;   // the reference maps a failed launch to this (snappy_compress.c:618-623)
+}
+
+}  // namespace
+
+snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host_buffer_context* output, uint32_t block_size,
+                                  struct program_runtime* runtime)
+{
+    double t0 = now_seconds();
+    if (!input || !output || !runtime) return SNAPPY_INVALID_INPUT;
+    runtime->d_alloc = runtime->load = runtime->copy_in = runtime->run = runtime->copy_out = runtime->d_free = 0.0;
+    if (!block_size_ok(block_size)) {
+        fprintf(stderr, "snappy_hip: block size %u is outside 1..65535 (16-bit hash table entries)\n", block_size);
+        return SNAPPY_INVALID_INPUT;
+    }
+    if (input->length > 0xffffffffull) {
+        fprintf(stderr, "snappy_hip: input of %lu bytes does not fit the format's uint32 length\n", input->length);
+        return SNAPPY_BUFFER_TOO_SMALL;
+    }
+    const uint64_t n = input->length;
+    const uint64_t nb = snappy_hip_num_blocks(n, block_size);
+    int gpus = requested_gpus();
+    if (gpus <= 0) {
+        fprintf(stderr, "snappy_hip: no HIP device available; the -d path has no CPU fallback\n");
+        return SNAPPY_INVALID_INPUT;
+    }
+    if ((uint64_t)gpus > nb) gpus = nb ? (int)nb : 1;
+
+    // partition: contiguous block ranges per device (snappy_compress.c:494-520)
+    const uint64_t per = nb ? (nb + gpus - 1) / gpus : 0;
+    std::vector<CompressShard> sh(gpus);
+    for (int g = 0; g < gpus; ++g) {
+        sh[g].first_block = (uint64_t)g * per;
+        const uint64_t last = std::min(nb, sh[g].first_block + per);
+        sh[g].num_blocks = last > sh[g].first_block ? last - sh[g].first_block : 0;
+        sh[g].in_off = sh[g].first_block * block_size;
+        sh[g].in_len = sh[g].num_blocks ? std::min<uint64_t>(n - sh[g].in_off, sh[g].num_blocks * (uint64_t)block_size) : 0;
+    }
+    uint8_t hdr[10];
+    const uint32_t hdr_len = snappy_hip_write_header(hdr, (uint32_t)n, block_size);   // :523-525
+    const uint32_t stride = snappy_hip_slot_stride(block_size);
+    runtime->pre += now_seconds() - t0;
+
+    // alloc (dpu_alloc, :535)
+    t0 = now_seconds();
+    int rc = for_each_device(gpus, [&](int g) -> int {
+        CompressShard& s = sh[g];
+        HIP_TRY(hipSetDevice(g));
+        if (!s.num_blocks) return 0;
+        HIP_TRY(hipMalloc((void**)&s.d_in, s.in_len + 16));
+        HIP_TRY(hipMalloc((void**)&s.d_slots, s.num_blocks * (uint64_t)stride));
+        HIP_TRY(hipMalloc((void**)&s.d_bytes, s.num_blocks * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&s.d_offsets, (s.num_blocks + 1) * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc((void**)&s.d_stream_len, sizeof(uint64_t)));
+        HIP_TRY(hipMalloc((void**)&s.d_stream, snappy_hip_stream_bound(s.in_len, block_size)));
+        return 0;
+    });
+    runtime->d_alloc = now_seconds() - t0;
+    if (rc) return report("device allocation", rc);
+
+    // load (dpu_load, :541): force the code object onto each device
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        HIP_TRY(hipSetDevice(g));
+        hipFuncAttributes fa;
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_kernel)));
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::gather_slots_kernel)));
+        return 0;
+    });
+    runtime->load = now_seconds() - t0;
+    if (rc) return report("code object load", rc);
+
+    // copy in (:547-612)
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        CompressShard& s = sh[g];
+        HIP_TRY(hipSetDevice(g));
+        if (s.num_blocks) HIP_TRY(hipMemcpy(s.d_in, input->buffer + s.in_off, s.in_len, hipMemcpyHostToDevice));
+        return 0;
+    });
+    runtime->copy_in = now_seconds() - t0;
+    if (rc) return report("host-to-device copy", rc);
+
+    // run (dpu_launch, :618)
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        CompressShard& s = sh[g];
+        HIP_TRY(hipSetDevice(g));
+        if (!s.num_blocks) return 0;
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        int r = snappy_hip_compress_blocks(s.d_in, s.in_len, block_size, s.d_slots, stride, s.d_bytes, nullptr);
+        if (r) return r;
+        r = snappy_hip_compact(s.d_slots, stride, s.d_bytes, s.in_len, block_size, s.d_stream, s.d_offsets, s.d_stream_len, nullptr);
+        if (r) return r;
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(&s.kernel_ms, e0, e1));
+        HIP_TRY(hipEventDestroy(e0));
+        HIP_TRY(hipEventDestroy(e1));
+        return 0;
+    });
+    runtime->run = now_seconds() - t0;
+    if (rc) return report("kernel launch", rc);
+
+    // copy out + host-side concat (:633-704)
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        CompressShard& s = sh[g];
+        HIP_TRY(hipSetDevice(g));
+        if (!s.num_blocks) return 0;
+        HIP_TRY(hipMemcpy(&s.stream_len, s.d_stream_len, sizeof(uint64_t), hipMemcpyDeviceToHost));
+        uint8_t tmp[10];
+        s.local_hdr = snappy_hip_write_header(tmp, (uint32_t)s.in_len, block_size);
+        return 0;
+    });
+    if (rc) return report("device-to-host copy", rc);
+    uint64_t total = hdr_len;
+    for (auto& s : sh) {
+        s.out_off = total;
+        if (s.num_blocks) total += s.stream_len - s.local_hdr;
+    }
+    {
+        uint8_t* nbuf = (uint8_t*)realloc(output->buffer, total ? total : 1);
+        if (!nbuf) {
+            fprintf(stderr, "snappy_hip: cannot allocate %lu bytes for the output\n", (unsigned long)total);
+            return SNAPPY_BUFFER_TOO_SMALL;
+        }
+        output->buffer = nbuf;
+        output->curr = nbuf;
+        memcpy(nbuf, hdr, hdr_len);
+    }
+    rc = for_each_device(gpus, [&](int g) -> int {
+        CompressShard& s = sh[g];
+        HIP_TRY(hipSetDevice(g));
+        if (s.num_blocks)
+            HIP_TRY(hipMemcpy(output->buffer + s.out_off, s.d_stream + s.local_hdr, s.stream_len - s.local_hdr, hipMemcpyDeviceToHost));
+        return 0;
+    });
+    output->length = total;
+    output->curr = output->buffer + total;
+    runtime->copy_out = now_seconds() - t0;
+    if (rc) return report("device-to-host copy", rc);
+
+    for (int g = 0; g < gpus; ++g)   // analogue of the per-tasklet log lines (dpu-compress/dpu_task.c:88)
+        printf("GPU %d: %f s, %lu bytes\n", g, sh[g].kernel_ms / 1000.0, (unsigned long)sh[g].in_len);
+
+    // free (dpu_free, :707)
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        CompressShard& s = sh[g];
+        HIP_TRY(hipSetDevice(g));
+        (void)hipFree(s.d_in);
+        (void)hipFree(s.d_slots);
+        (void)hipFree(s.d_bytes);
+        (void)hipFree(s.d_offsets);
+        (void)hipFree(s.d_stream_len);
+        (void)hipFree(s.d_stream);
+        return 0;
+    });
+    runtime->d_free = now_seconds() - t0;
+    return rc ? report("free", rc) : SNAPPY_OK;
+}
+
+snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct host_buffer_context* output,
+                                    struct program_runtime* runtime)
+{
+    double t0 = now_seconds();
+    if (!input || !output || !runtime) return SNAPPY_INVALID_INPUT;
+    runtime->d_alloc = runtime->load = runtime->copy_in = runtime->run = runtime->copy_out = runtime->d_free = 0.0;
+
+    // block-size varint (snappy_decompress.c:298-303)
+    const uint8_t* const buf = input->buffer;
+    const uint64_t in_total = input->length;
+    uint64_t at = (uint64_t)(input->curr - input->buffer);
+    uint32_t bs = 0;
+    const uint32_t used = (at <= in_total) ? get_varint32(buf + at, in_total - at, &bs) : 0;
+    if (!used) {
+        fprintf(stderr, "Failed to read decompressed block size\n");
+        return SNAPPY_INVALID_INPUT;
+    }
+    at += used;
+    input->curr += used;
+    const uint64_t total = output->length;
+    if (total == 0) {
+        runtime->pre += now_seconds() - t0;
+        return (at == in_total) ? SNAPPY_OK : SNAPPY_INVALID_INPUT;
+    }
+    if (!block_size_ok(bs)) {
+        fprintf(stderr, "snappy_hip: block size %u in the stream is outside 1..65535\n", bs);
+        return SNAPPY_INVALID_INPUT;
+    }
+    // host pre-scan of the size chain (:306-341)
+    const uint64_t nb = snappy_hip_num_blocks(total, bs);
+    std::vector<uint64_t> off(nb + 1);
+    for (uint64_t i = 0; i < nb; ++i) {
+        if (at + 4 > in_total) {
+            fprintf(stderr, "snappy_hip: truncated stream (block %lu of %lu)\n", (unsigned long)i, (unsigned long)nb);
+            return SNAPPY_INVALID_INPUT;
+        }
+        off[i] = at;
+        at += 4 + (uint64_t)le32_host(buf + at);
+    }
+    off[nb] = at;
+    if (at != in_total) {
+        fprintf(stderr, "snappy_hip: size chain ends at %lu, stream has %lu bytes\n", (unsigned long)at, (unsigned long)in_total);
+        return SNAPPY_INVALID_INPUT;
+    }
+    int gpus = requested_gpus();
+    if (gpus <= 0) {
+        fprintf(stderr, "snappy_hip: no HIP device available; the -d path has no CPU fallback\n");
+        return SNAPPY_INVALID_INPUT;
+    }
+    if ((uint64_t)gpus > nb) gpus = (int)nb;
+    const uint64_t per = (nb + gpus - 1) / gpus;
+    std::vector<DecompressShard> sh(gpus);
+    for (int g = 0; g < gpus; ++g) {
+        DecompressShard& s = sh[g];
+        s.first_block = (uint64_t)g * per;
+        const uint64_t last = std::min(nb, s.first_block + per);
+        s.num_blocks = last > s.first_block ? last - s.first_block : 0;
+        if (!s.num_blocks) continue;
+        s.in_off = off[s.first_block];
+        s.in_len = off[last] - s.in_off;
+        s.out_off = s.first_block * bs;
+        s.out_len = std::min<uint64_t>(total - s.out_off, s.num_blocks * (uint64_t)bs);
+        s.rel_off.resize(s.num_blocks);
+        for (uint64_t i = 0; i < s.num_blocks; ++i) s.rel_off[i] = off[s.first_block + i] - s.in_off;
+    }
+    runtime->pre += now_seconds() - t0;
+
+    t0 = now_seconds();
+    int rc = for_each_device(gpus, [&](int g) -> int {
+        DecompressShard& s = sh[g];
+        HIP_TRY(hipSetDevice(g));
+        if (!s.num_blocks) return 0;
+        HIP_TRY(hipMalloc((void**)&s.d_stream, s.in_len + 16));
+        HIP_TRY(hipMalloc((void**)&s.d_boff, s.num_blocks * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc((void**)&s.d_out, s.out_len + 16));
+        HIP_TRY(hipMalloc((void**)&s.d_status, s.num_blocks * sizeof(uint32_t)));
+        return 0;
+    });
+    runtime->d_alloc = now_seconds() - t0;
+    if (rc) return report("device allocation", rc);
+
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        HIP_TRY(hipSetDevice(g));
+        hipFuncAttributes fa;
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel)));
+        return 0;
+    });
+    runtime->load = now_seconds() - t0;
+    if (rc) return report("code object load", rc);
+
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        DecompressShard& s = sh[g];
+        HIP_TRY(hipSetDevice(g));
+        if (!s.num_blocks) return 0;
+        HIP_TRY(hipMemcpy(s.d_stream, buf + s.in_off, s.in_len, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s.d_boff, s.rel_off.data(), s.num_blocks * sizeof(uint64_t), hipMemcpyHostToDevice));
+        return 0;
+    });
+    runtime->copy_in = now_seconds() - t0;
+    if (rc) return report("host-to-device copy", rc);
+
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        DecompressShard& s = sh[g];
+        HIP_TRY(hipSetDevice(g));
+        if (!s.num_blocks) return 0;
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        int r = snappy_hip_decompress_blocks(s.d_stream, s.in_len, s.d_boff, s.out_len, bs, s.d_out, s.d_status, nullptr);
+        if (r) return r;
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(&s.kernel_ms, e0, e1));
+        HIP_TRY(hipEventDestroy(e0));
+        HIP_TRY(hipEventDestroy(e1));
+        return 0;
+    });
+    runtime->run = now_seconds() - t0;
+    if (rc) return report("kernel launch", rc);
+
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        DecompressShard& s = sh[g];
+        HIP_TRY(hipSetDevice(g));
+        if (!s.num_blocks) return 0;
+        std::vector<uint32_t> st(s.num_blocks);
+        HIP_TRY(hipMemcpy(st.data(), s.d_status, s.num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < s.num_blocks; ++i)
+            if (st[i] != SNAPPY_HIP_BLOCK_OK) s.bad = true;
+        HIP_TRY(hipMemcpy(output->buffer + s.out_off, s.d_out, s.out_len, hipMemcpyDeviceToHost));   // :463
+        return 0;
+    });
+    runtime->copy_out = now_seconds() - t0;
+    if (rc) return report("device-to-host copy", rc);
+
+    for (int g = 0; g < gpus; ++g)
+        printf("GPU %d: %f s, %lu bytes\n", g, sh[g].kernel_ms / 1000.0, (unsigned long)sh[g].in_len);
+
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        DecompressShard& s = sh[g];
+        HIP_TRY(hipSetDevice(g));
+        (void)hipFree(s.d_stream);
+        (void)hipFree(s.d_boff);
+        (void)hipFree(s.d_out);
+        (void)hipFree(s.d_status);
+        return 0;
+    });
+    runtime->d_free = now_seconds() - t0;
+    if (rc) return report("free", rc);
+    for (auto& s : sh)
+        if (s.bad) {
+            fprintf(stderr, "snappy_hip: malformed block in the stream\n");
+            return SNAPPY_INVALID_INPUT;
+        }
+    output->curr = output->buffer + total;
+    return SNAPPY_OK;
+}
+
+}  // extern "C"

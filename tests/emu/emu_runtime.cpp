@@ -1,0 +1,232 @@
+// Fiber-based lockstep wave emulator + C entry points that drive the real kernel source on the CPU.
+// Test infrastructure only (see tests/emu/hip/hip_runtime.h).
+#include <hip/hip_runtime.h>   // resolves to tests/emu/hip/hip_runtime.h via -I
+#include <ucontext.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <vector>
+
+#include "snappy_kernels.hpp"
+
+namespace emu {
+
+constexpr int kStack = 256 * 1024;
+
+struct Fiber {
+    ucontext_t ctx;
+    std::vector<uint8_t> stack;
+    Dim tid;
+    bool done = false;
+    bool started = false;
+};
+
+struct WaveSlot {
+    uint64_t val[64];
+    uint32_t arg[64];
+    uint64_t res[2][64];
+    int arrived = 0;
+    int active = 0;
+    uint32_t gen = 0;
+    int site = -1;
+    Op op = OP_BARRIER;
+};
+
+static std::vector<Fiber> g_fibers;
+static std::vector<WaveSlot> g_waves;
+static ucontext_t g_sched;
+static int g_cur = -1;
+static Dim g_bidx, g_gdim, g_bdim;
+static std::function<void()> g_body;
+static int g_wg_active = 0, g_sync_arrived = 0, g_sync_site = -1;
+static uint32_t g_sync_gen = 0;
+static uint8_t g_dyn_lds[65536 + 64] __attribute__((aligned(64)));
+
+const Dim& tidx() { return g_fibers[g_cur].tid; }
+const Dim& bidx() { return g_bidx; }
+const Dim& gdim() { return g_gdim; }
+const Dim& bdim() { return g_bdim; }
+void* dynamic_lds() { return g_dyn_lds; }
+
+static void yield() { swapcontext(&g_fibers[g_cur].ctx, &g_sched); }
+
+static void complete(WaveSlot& w)
+{
+    uint64_t* r = w.res[w.gen & 1];
+    // participating lanes are exactly those that deposited (active ones)
+    int first = -1;
+    uint64_t ballot = 0;
+    for (int l = 0; l < 64; ++l)
+        if (w.arg[l] != 0xdeadbeefu) {
+            if (first < 0) first = l;
+            if (w.op == OP_BALLOT && w.val[l]) ballot |= 1ull << l;
+        }
+    for (int l = 0; l < 64; ++l) {
+        if (w.arg[l] == 0xdeadbeefu) continue;
+        switch (w.op) {
+        case OP_FIRSTLANE: r[l] = w.val[first]; break;
+        case OP_BALLOT: r[l] = ballot; break;
+        case OP_READLANE: r[l] = w.val[w.arg[l] & 63]; break;
+        case OP_SHFL_UP: r[l] = (l >= (int)w.arg[l]) ? w.val[l - w.arg[l]] : w.val[l]; break;
+        case OP_BARRIER: r[l] = 0; break;
+        }
+    }
+    for (int l = 0; l < 64; ++l) w.arg[l] = 0xdeadbeefu;
+    w.arrived = 0;
+    w.site = -1;
+    w.gen++;
+}
+
+uint64_t collective(Op op, uint64_t value, uint32_t arg, int site)
+{
+    const uint32_t t = g_fibers[g_cur].tid.x;
+    WaveSlot& w = g_waves[t >> 6];
+    const int lane = t & 63;
+    if (w.arrived == 0) {
+        w.site = site;
+        w.op = op;
+    } else if (w.site != site || w.op != op) {
+        fprintf(stderr, "emu: divergent collective: lane %d at line %d, wave waiting at line %d\n", lane, site, w.site);
+        abort();
+    }
+    w.val[lane] = value;
+    w.arg[lane] = arg;
+    w.arrived++;
+    const uint32_t gen = w.gen;
+    if (w.arrived == w.active)
+        complete(w);
+    else
+        while (w.gen == gen) yield();
+    return w.res[gen & 1][lane];
+}
+
+void syncthreads(int site)
+{
+    if (g_sync_arrived == 0)
+        g_sync_site = site;
+    else if (g_sync_site != site) {
+        fprintf(stderr, "emu: divergent __syncthreads (line %d vs %d)\n", site, g_sync_site);
+        abort();
+    }
+    const uint32_t gen = g_sync_gen;
+    if (++g_sync_arrived == g_wg_active) {
+        g_sync_arrived = 0;
+        g_sync_gen++;
+    } else
+        while (g_sync_gen == gen) yield();
+}
+
+static void fiber_main()
+{
+    g_body();
+    Fiber& f = g_fibers[g_cur];
+    f.done = true;
+    WaveSlot& w = g_waves[f.tid.x >> 6];
+    w.active--;
+    g_wg_active--;
+    if (w.arrived > 0 && w.arrived == w.active) complete(w);
+    if (g_sync_arrived > 0 && g_sync_arrived == g_wg_active) {
+        g_sync_arrived = 0;
+        g_sync_gen++;
+    }
+    swapcontext(&f.ctx, &g_sched);
+}
+
+void launch(uint32_t grid, uint32_t block, const std::function<void()>& body)
+{
+    g_body = body;
+    g_gdim = Dim{grid, 1, 1};
+    g_bdim = Dim{block, 1, 1};
+    if (g_fibers.size() < block) g_fibers.resize(block);
+    for (uint32_t b = 0; b < grid; ++b) {
+        g_bidx = Dim{b, 0, 0};
+        g_waves.assign((block + 63) / 64, WaveSlot());
+        for (auto& w : g_waves)
+            for (int l = 0; l < 64; ++l) w.arg[l] = 0xdeadbeefu;
+        g_wg_active = (int)block;
+        g_sync_arrived = 0;
+        for (uint32_t t = 0; t < block; ++t) {
+            Fiber& f = g_fibers[t];
+            f.tid = Dim{t, 0, 0};
+            f.done = false;
+            if (f.stack.empty()) f.stack.resize(kStack);
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack.data();
+            f.ctx.uc_stack.ss_size = f.stack.size();
+            f.ctx.uc_link = &g_sched;
+            makecontext(&f.ctx, fiber_main, 0);
+            g_waves[t >> 6].active++;
+        }
+        int remaining = (int)block;
+        while (remaining > 0) {
+            int progressed = 0;
+            for (uint32_t t = 0; t < block; ++t) {
+                Fiber& f = g_fibers[t];
+                if (f.done) continue;
+                g_cur = (int)t;
+                swapcontext(&g_sched, &f.ctx);
+                if (f.done) remaining--;
+                progressed++;
+            }
+            if (!progressed) break;
+        }
+    }
+}
+
+}  // namespace emu
+
+// ---------------------------------------------------------------------------
+// C entry points used by tests/test_emulated_kernels.py
+// ---------------------------------------------------------------------------
+extern "C" {
+
+// Runs compress_blocks_kernel + scan + gather on the CPU emulator.  Returns stream length.
+uint64_t emu_compress(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_t* stream, uint64_t stream_cap)
+{
+    const uint64_t need = 4ull + 32ull + block_size + block_size / 6;
+    const uint32_t stride = (uint32_t)((need + 15) & ~15ull);
+    const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
+    if (stream_cap < 10 + (uint64_t)nb * stride) return 0;
+    std::vector<uint8_t> slots((size_t)nb * stride + 64, 0xAA);
+    std::vector<uint32_t> bytes(nb + 1, 0);
+    std::vector<uint64_t> offsets(nb + 1, 0);
+    uint64_t stream_len = 0;
+    // padded copy so the same (unaligned, slightly over-reading) loads stay inside the allocation
+    std::vector<uint8_t> inbuf(n + 64, 0x55);
+    if (n) memcpy(inbuf.data(), in, n);
+    if (nb)
+        emu::launch(nb, 64, [&] {
+            snappy_hip::compress_blocks_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb);
+        });
+    emu::launch(1, 1024, [&] {
+        snappy_hip::scan_block_bytes_kernel(bytes.data(), nb, (uint32_t)n, block_size, stream, offsets.data(), &stream_len);
+    });
+    if (nb)
+        emu::launch(nb, 256, [&] {
+            snappy_hip::gather_slots_kernel(slots.data(), stride, bytes.data(), offsets.data(), stream, nb);
+        });
+    return stream_len;
+}
+
+// Runs index_streams_kernel + decompress_blocks_kernel on the emulator.
+// Returns 0 on success, 1 if any block (or the chain) is invalid.
+int emu_decompress(const uint8_t* stream, uint64_t stream_len, uint32_t total_len, uint32_t block_size, uint32_t header_len,
+                   uint8_t* out)
+{
+    const uint32_t nb = block_size ? (uint32_t)(((uint64_t)total_len + block_size - 1) / block_size) : 0;
+    if (nb == 0) return stream_len == header_len ? 0 : 1;
+    std::vector<uint64_t> boff(nb, 0);
+    uint32_t result[2] = {7, 7};
+    snappy_hip::StreamDesc d{stream, stream_len, boff.data(), result, total_len, block_size, header_len, nb};
+    emu::launch(1, 64, [&] { snappy_hip::index_streams_kernel(&d, 1); });
+    if (result[0] != 0 || result[1] != nb) return 1;
+    std::vector<uint32_t> status(nb, 9);
+    emu::launch(nb, 64, [&] {
+        snappy_hip::decompress_blocks_kernel(stream, stream_len, boff.data(), total_len, block_size, out, status.data(), nb);
+    });
+    for (uint32_t i = 0; i < nb; ++i)
+        if (status[i] != 0) return 1;
+    return 0;
+}
+}

@@ -1,0 +1,52 @@
+// Test-only stand-in for <hip/hip_runtime.h>: lets g++ compile the UNMODIFIED kernel source
+// (pim-compression_amd/csrc/snappy_kernels.hpp) for a lockstep CPU wave emulator, so the kernel
+// logic can be fuzzed against the oracle in the GPU-less container.  Not part of the product and
+// never on any GPU path.  Every lane of a workgroup is a ucontext fiber; wave collectives
+// (ballot / readlane / readfirstlane / shfl / wave_barrier) rendezvous the 64 lanes of a wave,
+// __syncthreads() the whole workgroup.  The emulator aborts if a collective is reached from
+// divergent control flow (lanes of one wave waiting at different call sites).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __constant__ static const
+#define __launch_bounds__(...)
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(emu::dynamic_lds());
+
+struct uint4 {
+    uint32_t x, y, z, w;
+};
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+
+namespace emu {
+struct Dim {
+    uint32_t x, y, z;
+};
+const Dim& tidx();
+const Dim& bidx();
+const Dim& gdim();
+const Dim& bdim();
+void* dynamic_lds();
+
+enum Op { OP_FIRSTLANE = 1, OP_BALLOT, OP_READLANE, OP_SHFL_UP, OP_BARRIER };
+uint64_t collective(Op op, uint64_t value, uint32_t arg, int site);
+void syncthreads(int site);
+}  // namespace emu
+
+#define threadIdx (emu::tidx())
+#define blockIdx (emu::bidx())
+#define gridDim (emu::gdim())
+#define blockDim (emu::bdim())
+
+#define __builtin_amdgcn_readfirstlane(v) ((uint32_t)emu::collective(emu::OP_FIRSTLANE, (uint64_t)(uint32_t)(v), 0, __LINE__))
+#define __builtin_amdgcn_readlane(v, l) ((int)emu::collective(emu::OP_READLANE, (uint64_t)(uint32_t)(v), (uint32_t)(l), __LINE__))
+#define __builtin_amdgcn_wave_barrier() ((void)emu::collective(emu::OP_BARRIER, 0, 0, __LINE__))
+#define __ballot(p) ((unsigned long long)emu::collective(emu::OP_BALLOT, (uint64_t)((p) ? 1 : 0), 0, __LINE__))
+#define __shfl_up(v, d) ((int)emu::collective(emu::OP_SHFL_UP, (uint64_t)(uint32_t)(v), (uint32_t)(d), __LINE__))
+#define __syncthreads() emu::syncthreads(__LINE__)

@@ -1,0 +1,53 @@
+"""ctypes binding of the CPU wave emulator build of the kernels (tests/emu). Test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+_LIB = None
+
+
+def build():
+    src = os.path.join(HERE, "emu", "emu_runtime.cpp")
+    out = os.path.join(HERE, "emu", "libsnappy_emu.so")
+    deps = [src, os.path.join(HERE, "emu", "hip", "hip_runtime.h"),
+            os.path.join(ROOT, "pim-compression_amd", "csrc", "snappy_kernels.hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(HERE, "emu"),
+                               "-I" + os.path.join(ROOT, "pim-compression_amd", "csrc"), src, "-o", out])
+    return out
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        L.emu_compress.restype = ctypes.c_uint64
+        L.emu_compress.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64]
+        L.emu_decompress.restype = ctypes.c_int
+        L.emu_decompress.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                     ctypes.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def compress(data, block_size=32768):
+    a = np.frombuffer(data, dtype=np.uint8).copy() if len(data) else np.zeros(1, dtype=np.uint8)
+    n = len(data)
+    nb = (n + block_size - 1) // block_size
+    stride = (4 + 32 + block_size + block_size // 6 + 15) & ~15
+    cap = 10 + nb * stride
+    out = np.zeros(cap + 16, dtype=np.uint8)
+    got = lib().emu_compress(a.ctypes.data, n, block_size, out.ctypes.data, cap)
+    assert got > 0
+    return out[:got].tobytes()
+
+
+def decompress(stream, total_len, block_size, header_len):
+    a = np.frombuffer(stream, dtype=np.uint8).copy()
+    out = np.zeros(max(total_len, 1) + 16, dtype=np.uint8)
+    st = lib().emu_decompress(a.ctypes.data, a.size, total_len, block_size, header_len, out.ctypes.data)
+    return st, out[:total_len].tobytes()

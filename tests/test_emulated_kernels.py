@@ -1,0 +1,60 @@
+"""CPU tests: the UNMODIFIED HIP kernel source (pim-compression_amd/csrc/snappy_kernels.hpp) compiled
+for the lockstep wave emulator in tests/emu and compared with the oracle.  This is logic coverage for the
+GPU-less container; the real parity tests are the -m gpu ones through the C ABI."""
+import pytest
+
+import datagen
+import emu_lib as emu
+import oracle_lib as oracle
+from conftest import golden_bytes
+
+
+@pytest.mark.parametrize("name", ["alice", "coding", "terror2"])
+def test_emulated_golden_both_directions(name):
+    txt, snp = golden_bytes(name + ".txt"), golden_bytes(name + ".snappy")
+    assert emu.compress(txt, 32768) == snp
+    total, bs, hdr = oracle.read_header(snp)
+    st, out = emu.decompress(snp, total, bs, hdr)
+    assert st == 0 and out == txt
+
+
+def test_emulated_edges_vs_oracle():
+    text = golden_bytes("plrabn12.txt")
+    for name, data in datagen.edge_cases(text):
+        data = data[:12000]
+        for bs in (64, 257, 4096, 32768, 65535):
+            if len(data) > 3000 and bs < 4096:
+                continue
+            ref = oracle.compress(data, bs)
+            assert emu.compress(data, bs) == ref, (name, bs)
+            total, got_bs, hdr = oracle.read_header(ref)
+            st, out = emu.decompress(ref, total, got_bs, hdr)
+            assert st == 0 and out == data, (name, bs)
+
+
+def test_emulated_long_runs_and_split_copies():
+    # long matches exercise the 64/60/rest copy split (snappy_compress.c:254-272) and 256-byte extension rounds
+    for n in (67, 68, 69, 131, 132, 1000, 40000):
+        data = b"abcd" + bytes(n)
+        ref = oracle.compress(data, 65535)
+        assert emu.compress(data, 65535) == ref, n
+        total, bs, hdr = oracle.read_header(ref)
+        st, out = emu.decompress(ref, total, bs, hdr)
+        assert st == 0 and out == data
+
+
+def test_emulated_decoder_is_strict():
+    # copy reaching before the block start
+    body = bytes([0x00, 0x41, (3 << 2) | 2, 9, 0])
+    stream = bytes([5, 0x80, 0x80, 0x02]) + len(body).to_bytes(4, "little") + body
+    st, _ = emu.decompress(stream, 5, 32768, 4)
+    assert st == 1
+    # literal longer than the block's compressed size
+    body = bytes([0x10, 0x41])
+    stream = bytes([5, 0x80, 0x80, 0x02]) + len(body).to_bytes(4, "little") + body
+    st, _ = emu.decompress(stream, 5, 32768, 4)
+    assert st == 1
+    # truncated chain
+    good = oracle.compress(b"hello hello hello hello", 32768)
+    st, _ = emu.decompress(good[:-1], 23, 32768, 4)
+    assert st == 1

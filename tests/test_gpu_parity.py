@@ -1,0 +1,190 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI of libsnappy_hip.so, against the oracle
+and the reference's golden vectors.  Bit-exact: identical .snappy bytes on compress, identical plaintext on
+decompress."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import datagen
+import oracle_lib as oracle
+from conftest import GOLDEN_PAIRS, XML_TXT_LEN, XML_TXT_SHA256, golden_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def shb():
+    import torch
+    import __graft_entry__ as entry
+    entry.build_hip()
+    import snappy_hip_binding as binding
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    assert binding.lib().snappy_hip_device_count() >= 1
+    return binding
+
+
+def to_dev(data):
+    import torch
+    a = np.frombuffer(data, dtype=np.uint8).copy() if len(data) else np.zeros(0, dtype=np.uint8)
+    t = torch.zeros(len(data) + 16, dtype=torch.uint8, device="cuda")
+    if len(data):
+        t[:len(data)] = torch.from_numpy(a).cuda()
+    return t
+
+
+def gpu_compress(shb, data, bs):
+    d = to_dev(data)
+    return bytes(shb.compress_resident(d, bs, n=len(data)).cpu().numpy())
+
+
+def gpu_decompress(shb, stream):
+    d = to_dev(stream)
+    st, out = shb.decompress_resident(d, stream_len=len(stream))
+    return st, bytes(out.cpu().numpy())
+
+
+# ---- reference golden vectors (reference snappy/Makefile:54-56 does the decompress half) -------------
+
+@pytest.mark.parametrize("name", GOLDEN_PAIRS)
+def test_decompress_golden(shb, name):
+    st, out = gpu_decompress(shb, golden_bytes(name + ".snappy"))
+    assert st == 0
+    assert out == golden_bytes(name + ".txt")
+
+
+@pytest.mark.parametrize("name", GOLDEN_PAIRS)
+def test_compress_golden(shb, name):
+    assert gpu_compress(shb, golden_bytes(name + ".txt"), 32768) == golden_bytes(name + ".snappy")
+
+
+def test_xml_golden_both_directions(shb):
+    s = golden_bytes("xml.snappy")
+    st, out = gpu_decompress(shb, s)
+    assert st == 0 and len(out) == XML_TXT_LEN
+    assert hashlib.sha256(out).hexdigest() == XML_TXT_SHA256
+    assert gpu_compress(shb, out, 32768) == s
+
+
+# ---- drop-in pair with host buffers (what dpu_snappy.c's main() calls) --------------------------------
+
+@pytest.mark.parametrize("name", ["alice", "terror2", "world192"])
+def test_dropin_pair_host_buffers(shb, name):
+    txt, snp = golden_bytes(name + ".txt"), golden_bytes(name + ".snappy")
+    st, stream, rt = shb.compress_host(txt, 32768)
+    assert st == 0 and stream == snp
+    assert all(v >= 0 for v in rt.values()) and rt["run"] > 0 and rt["copy_in"] > 0
+    st, plain, rt = shb.decompress_host(snp)
+    assert st == 0 and plain == txt
+    assert rt["run"] > 0
+
+
+def test_dropin_rejects_bad_block_size_and_streams(shb):
+    st, _, _ = shb.compress_host(b"x" * 100, 0)
+    assert st != 0
+    st, _, _ = shb.compress_host(b"x" * 100, 65536)
+    assert st != 0
+    good = golden_bytes("alice.snappy")
+    st, _, _ = shb.decompress_host(good[:-3])
+    assert st != 0
+    bad = bytearray(good)
+    bad[9] = 0xFE   # corrupt the first tag into a copy-2 with nothing before it
+    st, _, _ = shb.decompress_host(bytes(bad))
+    assert st != 0
+    st, out, _ = shb.decompress_host(oracle.compress(b"", 32768))
+    assert st == 0 and out == b""
+
+
+# ---- oracle parity on edge cases and every block size -------------------------------------------------
+
+def test_edges_all_block_sizes_vs_oracle(shb):
+    text = golden_bytes("plrabn12.txt")
+    for name, data in datagen.edge_cases(text):
+        for bs in datagen.BLOCK_SIZES:
+            if len(data) > 80_000 and bs < 1000:
+                continue
+            ref = oracle.compress(data, bs)
+            got = gpu_compress(shb, data, bs) if len(data) else ref
+            assert got == ref, (name, bs)
+            st, out = gpu_decompress(shb, ref)
+            assert st == 0 and out == data, (name, bs)
+
+
+def test_unaligned_and_odd_block_sizes(shb):
+    data = golden_bytes("world192.txt")[:300_001]
+    for bs in (65535, 32767, 12345, 4097, 999, 77):
+        ref = oracle.compress(data, bs, threads=8)
+        assert gpu_compress(shb, data, bs) == ref, bs
+        st, out = gpu_decompress(shb, ref)
+        assert st == 0 and out == data, bs
+
+
+def test_decoder_strictness(shb):
+    body = bytes([0x00, 0x41, (3 << 2) | 2, 9, 0])                      # offset before block start
+    s1 = bytes([5, 0x80, 0x80, 0x02]) + len(body).to_bytes(4, "little") + body
+    body = bytes([0x10, 0x41])                                          # literal overruns the block
+    s2 = bytes([5, 0x80, 0x80, 0x02]) + len(body).to_bytes(4, "little") + body
+    body = bytes([0x00, 0x41, (3 << 2) | 2, 0, 0])                      # zero offset
+    s3 = bytes([5, 0x80, 0x80, 0x02]) + len(body).to_bytes(4, "little") + body
+    for s in (s1, s2, s3):
+        st, _ = gpu_decompress(shb, s)
+        assert st == 1
+    # COPY_4 elements are accepted (the compressor never emits them, snappy_decompress.c:278-283)
+    body = bytes([0x0C, 0x61, 0x62, 0x63, 0x64, (3 << 2) | 3, 4, 0, 0, 0])
+    s4 = bytes([8, 0x80, 0x80, 0x02]) + len(body).to_bytes(4, "little") + body
+    st, out = gpu_decompress(shb, s4)
+    assert st == 0 and out == b"abcdabcd"
+    assert oracle.decompress(s4) == (0, b"abcdabcd")
+
+
+def test_batched_index_matches_scan_offsets(shb):
+    """Two independent computations of the same thing: the compressor's exclusive scan of block sizes and
+    the decompressor's walk of the u32 size chain."""
+    import torch
+    items = [golden_bytes("plrabn12.txt"), golden_bytes("world192.txt"), datagen.random_bytes(100_000)]
+    entries, keep = [], []
+    for data in items:
+        d_in = to_dev(data)
+        ws = shb.CompressWorkspace(len(data), 32768)
+        d_stream = torch.empty(ws.stream_capacity(len(data)) + 16, dtype=torch.uint8, device="cuda")
+        shb.compress_blocks(d_in, len(data), ws)
+        shb.compact(len(data), ws, d_stream)
+        slen = int(ws.stream_len.item())
+        nb = shb.num_blocks(len(data), 32768)
+        boff = torch.zeros(nb, dtype=torch.int64, device="cuda")
+        res = torch.full((2,), 7, dtype=torch.int32, device="cuda")
+        hdr = len(shb.write_header(len(data), 32768))
+        entries.append(dict(stream=d_stream, stream_len=slen, block_offsets=boff, result=res, total_len=len(data),
+                            block_size=32768, header_len=hdr, num_blocks=nb))
+        keep.append((ws, d_stream, boff, res, nb, slen))
+    descs = shb.make_stream_descs(entries)
+    shb.index_streams(descs, len(entries))
+    for ws, d_stream, boff, res, nb, slen in keep:
+        assert res.cpu().tolist() == [0, nb]
+        assert torch.equal(boff, ws.offsets[:nb])
+        assert int(ws.offsets[nb].item()) == slen
+        assert int(ws.block_bytes[:nb].sum().item()) + int(ws.offsets[0].item()) == slen
+
+
+# ---- BASELINE.json full size: one 1 GiB Silesia-mix container -----------------------------------------
+
+def test_full_size_container_roundtrip_and_oracle(shb):
+    import torch
+    import silesia_mix
+    st, xml = gpu_decompress(shb, golden_bytes("xml.snappy"))
+    assert st == 0 and hashlib.sha256(xml).hexdigest() == XML_TXT_SHA256
+    unit = silesia_mix.build_unit(np.frombuffer(xml, dtype=np.uint8), seed=0)
+    n = 1 << 30
+    d_in = silesia_mix.container_from_unit(torch.from_numpy(unit.copy()).cuda(), n)
+    d_stream = shb.compress_resident(d_in, 32768, n=n)
+    st, d_out = shb.decompress_resident(d_stream)
+    assert st == 0
+    assert torch.equal(d_out[:n], d_in[:n])                      # encode -> decode round trip, on device
+    saving = 1.0 - d_stream.numel() / n
+    assert 0.3 < saving < 0.75, saving
+    # whole-container oracle comparison (multi-threaded oracle finishes in seconds)
+    host_in = d_in[:n].cpu().numpy()
+    ref = oracle.compress(host_in, 32768, threads=16)
+    got = d_stream.cpu().numpy()
+    assert got.size == len(ref)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == hashlib.sha256(ref).hexdigest()
