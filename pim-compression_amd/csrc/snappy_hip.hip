@@ -94,6 +94,14 @@ int for_each_device(int count, const std::function<int(int)>& fn)
     return 0;
 }
 
+constexpr int kDefaultCompressVariant = snappy_hip::kVariantGlobalScalar;
+
+int env_int(const char* name, int fallback)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : fallback;
+}
+
 int requested_gpus()
 {
     int have = 0;
@@ -175,8 +183,23 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
     const uint64_t nb = snappy_hip_num_blocks(input_len, block_size);
     if (nb == 0) return SNAPPY_HIP_OK;
     if (!d_in || !d_slots || !d_block_bytes) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
-    hipLaunchKernelGGL(snappy_hip::compress_blocks_kernel, dim3((uint32_t)nb), dim3(64), 0, (hipStream_t)stream, d_in,
-                       input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb);
+    // Tuning knobs (experiments / ablations): SNAPPY_HIP_COMPRESS_VARIANT = 0 global-vector, 1 global-scalar,
+    // 2 LDS-staged input; SNAPPY_HIP_EXTRA_LDS = extra dynamic LDS bytes per workgroup (lowers occupancy).
+    const int variant = env_int("SNAPPY_HIP_COMPRESS_VARIANT", kDefaultCompressVariant);
+    uint32_t lds = (uint32_t)env_int("SNAPPY_HIP_EXTRA_LDS", 0);
+    const dim3 grid((uint32_t)nb), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == snappy_hip::kVariantLdsInput) {
+        lds += ((block_size + 15u) & ~15u) + 16u;
+        hipLaunchKernelGGL(snappy_hip::compress_blocks_kernel<snappy_hip::kVariantLdsInput>, grid, block, lds, st, d_in,
+                           input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb);
+    } else if (variant == snappy_hip::kVariantGlobalScalar) {
+        hipLaunchKernelGGL(snappy_hip::compress_blocks_kernel<snappy_hip::kVariantGlobalScalar>, grid, block, lds, st, d_in,
+                           input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb);
+    } else {
+        hipLaunchKernelGGL(snappy_hip::compress_blocks_kernel<snappy_hip::kVariantGlobalVector>, grid, block, lds, st, d_in,
+                           input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb);
+    }
     HIP_TRY(hipGetLastError());
     return SNAPPY_HIP_OK;
 }
@@ -324,7 +347,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     rc = for_each_device(gpus, [&](int g) -> int {
         HIP_TRY(hipSetDevice(g));
         hipFuncAttributes fa;
-        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_kernel)));
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_kernel<kDefaultCompressVariant>)));
         HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::gather_slots_kernel)));
         return 0;
     });

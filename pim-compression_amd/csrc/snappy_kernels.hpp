@@ -163,14 +163,170 @@ __device__ __forceinline__ uint32_t match_extend(const uint8_t* __restrict__ blk
 }
 
 // ---------------------------------------------------------------------------
-// K1: compress.  grid-stride over blocks, one wavefront per block.
+// Input-access policies for K1.  The parse reads the block at (a) the cursor, sequentially, and
+// (b) hash-table candidates, randomly inside [0, cursor).  Where those bytes live decides the
+// latency of every serial step, so the kernel is templated on it.
 // ---------------------------------------------------------------------------
+
+// Block read straight from HBM/L2 with vector loads; LDS holds only the hash table (5 blocks/CU).
+struct InputGlobalVector {
+    const uint8_t* __restrict__ blk;
+    __device__ __forceinline__ void stage(const uint8_t* __restrict__ b, uint32_t, uint32_t, uint8_t*) { blk = b; }
+    __device__ __forceinline__ uint32_t u32(uint32_t p) const { return uld32(blk + p); }
+    __device__ __forceinline__ uint64_t u64(uint32_t p) const { return uld64(blk + p); }
+    __device__ __forceinline__ const uint8_t* bytes() const { return blk; }
+};
+
+// Same, but the wave-uniform reads go through the scalar cache (s_load_dwordx2/x4 on aligned dwords +
+// 64-bit shift), which returns into SGPRs directly.  `base16` is the 16-byte aligned container base.
+struct InputGlobalScalar {
+    const uint8_t* __restrict__ blk;
+    const uint8_t* __restrict__ base16;
+    uint64_t start;
+    __device__ __forceinline__ void stage(const uint8_t* __restrict__ b, uint32_t, uint32_t, uint8_t*) { blk = b; }
+    __device__ __forceinline__ uint32_t u32(uint32_t p) const
+    {
+        const uint64_t a = start + p;
+        const uint32_t* w = static_cast<const uint32_t*>(__builtin_assume_aligned(base16 + (a & ~3ull), 4));
+        const uint64_t two = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+        return (uint32_t)(two >> (8 * (uint32_t)(a & 3)));
+    }
+    __device__ __forceinline__ uint64_t u64(uint32_t p) const
+    {
+        const uint64_t a = start + p;
+        const uint32_t* w = static_cast<const uint32_t*>(__builtin_assume_aligned(base16 + (a & ~3ull), 4));
+        const uint32_t sh = 8 * (uint32_t)(a & 3);
+        const uint64_t lo = ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) >> sh;
+        const uint64_t hi = ((uint64_t)w[1] | ((uint64_t)w[2] << 32)) >> sh;
+        return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
+    }
+    __device__ __forceinline__ const uint8_t* bytes() const { return blk; }
+};
+
+// Block staged into LDS once (coalesced 16 B/lane), every later read is an LDS read.
+// 64 KiB of LDS per 32 KiB block (table + input): 2 blocks/CU, but ~10x lower read latency.
+struct InputLds {
+    const uint8_t* lds;
+    __device__ __forceinline__ void stage(const uint8_t* __restrict__ b, uint32_t n, uint32_t lane, uint8_t* buf)
+    {
+        uint32_t i = 16 * lane;
+        for (; i + 16 <= n; i += 16 * kWave) {
+            uint4 v;
+            __builtin_memcpy(&v, b + i, 16);
+            *reinterpret_cast<uint4*>(buf + i) = v;
+        }
+        for (; i < n; ++i) buf[i] = b[i];     // one lane, < 16 bytes
+        lds = buf;
+    }
+    __device__ __forceinline__ uint32_t u32(uint32_t p) const { return uld32(lds + p); }
+    __device__ __forceinline__ uint64_t u64(uint32_t p) const { return uld64(lds + p); }
+    __device__ __forceinline__ const uint8_t* bytes() const { return lds; }
+};
+
+// ---------------------------------------------------------------------------
+// K1: compress.  One wavefront per block (grid-stride).
+// ---------------------------------------------------------------------------
+template <class Input>
+__device__ __forceinline__ void compress_one_block(Input& in, const uint8_t* __restrict__ blk_global, uint32_t n,
+                                                   uint8_t* __restrict__ dst, uint16_t* table, uint8_t* stage_buf,
+                                                   uint32_t lane, uint32_t* __restrict__ block_bytes_out)
+{
+    // get_hash_table, snappy_compress.c:139-146 (+ shift, :288)
+    const uint32_t ts = table_entries_for(n);
+    const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;   // 32 - log2(ts)
+    {
+        uint4* t = reinterpret_cast<uint4*>(table);
+        for (uint32_t i = lane; i < ts / 8; i += kWave) t[i] = make_uint4(0, 0, 0, 0);
+    }
+    in.stage(blk_global, n, lane, stage_buf);
+    __syncthreads();
+    const uint8_t* blk = in.bytes();   // per-lane (vector) reads: match extension
+
+    uint32_t op = 4;          // :291 room for the u32 size prefix
+    uint32_t next_emit = 0;   // :298
+
+    if (n >= kInputMargin) {  // :301
+        const uint32_t limit = n - kInputMargin;
+        uint32_t ip = 1;      // :305
+        uint32_t cur = in.u32(ip);        // bytes at ip
+        for (;;) {
+            // ---- step 1: scan for a 4-byte match (:333-348) ----
+            uint32_t skip = 32;
+            uint32_t cand;
+            bool out_of_input = false;
+            for (;;) {
+                const uint32_t h = (cur * kHashMul) >> shift;
+                const uint32_t next_ip = ip + (skip++ >> 5);
+                if (next_ip > limit) {          // :342-343, before touching the table
+                    out_of_input = true;
+                    break;
+                }
+                const uint32_t nxt = in.u32(next_ip);
+                cand = uni((uint32_t)table[h]);
+                if (lane == 0) table[h] = (uint16_t)ip;
+                __builtin_amdgcn_wave_barrier();
+                if (cur == in.u32(cand)) break;
+                ip = next_ip;
+                cur = nxt;
+            }
+            if (out_of_input) break;
+
+            // ---- step 2: literal run [next_emit, ip) (:355); payload copied from global memory ----
+            op = emit_literal(dst, op, blk_global + next_emit, ip - next_emit, lane);
+
+            // ---- step 3: copy chain (:370-398) ----
+            bool again;
+            bool done = false;
+            uint32_t tail = 0;     // le32(ip+1) after the chain, for the next scan
+            do {
+                const uint32_t base = ip;
+                const uint32_t matched = 4 + match_extend(blk, cand + 4, ip + 4, n, lane);
+                ip += matched;
+                op = emit_copy(dst, op, base - cand, matched, lane);
+                next_emit = ip;
+                if (ip >= limit) {              // :388-389
+                    done = true;
+                    break;
+                }
+                const uint64_t w = in.u64(ip - 1);               // bytes ip-1 .. ip+6
+                const uint32_t prev_bytes = (uint32_t)w;
+                const uint32_t here = (uint32_t)(w >> 8);
+                tail = (uint32_t)(w >> 16);
+                const uint32_t hp = (prev_bytes * kHashMul) >> shift;
+                const uint32_t hc = (here * kHashMul) >> shift;
+                if (lane == 0) table[hp] = (uint16_t)(ip - 1);   // :391-392
+                __builtin_amdgcn_wave_barrier();
+                cand = uni((uint32_t)table[hc]);                 // :394-395
+                if (lane == 0) table[hc] = (uint16_t)ip;         // :397
+                __builtin_amdgcn_wave_barrier();
+                again = (here == in.u32(cand));                  // :396,:398
+            } while (again);
+            if (done) break;
+
+            ++ip;                                                // :400-401
+            cur = tail;
+        }
+    }
+
+    // emit_remainder (:405-410) and the size prefix (:412)
+    if (next_emit < n) op = emit_literal(dst, op, blk_global + next_emit, n - next_emit, lane);
+    if (lane == 0) {
+        st32(dst, op - 4);
+        *block_bytes_out = op;
+    }
+    __syncthreads();   // table (and the staged block) are rewritten by the next iteration
+}
+
+enum CompressVariant { kVariantGlobalVector = 0, kVariantGlobalScalar = 1, kVariantLdsInput = 2 };
+
+template <int kVariant>
 __global__ __launch_bounds__(64) void compress_blocks_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
                                                              uint32_t block_size, uint8_t* __restrict__ slots,
                                                              uint32_t slot_stride, uint32_t* __restrict__ block_bytes,
                                                              uint32_t num_blocks)
 {
     __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTableEntries];
+    HIP_DYNAMIC_SHARED(uint8_t, stage_buf)   // kVariantLdsInput: block_size rounded up to 16 (+16); else unused
     const uint32_t lane = threadIdx.x;
 
     for (uint32_t b = blockIdx.x; b < num_blocks; b += gridDim.x) {
@@ -179,89 +335,16 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(const uint8_t* __re
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
         const uint8_t* __restrict__ blk = in + start;
         uint8_t* __restrict__ dst = slots + (uint64_t)b * slot_stride;
-
-        // get_hash_table, snappy_compress.c:139-146 (+ shift, :288)
-        const uint32_t ts = table_entries_for(n);
-        const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;   // 32 - log2(ts)
-        {
-            uint4* t = reinterpret_cast<uint4*>(table);
-            for (uint32_t i = lane; i < ts / 8; i += kWave) t[i] = make_uint4(0, 0, 0, 0);
+        if constexpr (kVariant == kVariantGlobalScalar) {
+            InputGlobalScalar src{blk, in, start};
+            compress_one_block(src, blk, n, dst, table, stage_buf, lane, block_bytes + b);
+        } else if constexpr (kVariant == kVariantLdsInput) {
+            InputLds src{stage_buf};
+            compress_one_block(src, blk, n, dst, table, stage_buf, lane, block_bytes + b);
+        } else {
+            InputGlobalVector src{blk};
+            compress_one_block(src, blk, n, dst, table, stage_buf, lane, block_bytes + b);
         }
-        __syncthreads();
-
-        uint32_t op = 4;          // :291 room for the u32 size prefix
-        uint32_t next_emit = 0;   // :298
-
-        if (n >= kInputMargin) {  // :301
-            const uint32_t limit = n - kInputMargin;
-            uint32_t ip = 1;      // :305
-            uint32_t cur = uld32(blk + ip);        // bytes at ip
-            for (;;) {
-                // ---- step 1: scan for a 4-byte match (:333-348) ----
-                uint32_t skip = 32;
-                uint32_t cand;
-                bool out_of_input = false;
-                for (;;) {
-                    const uint32_t h = (cur * kHashMul) >> shift;
-                    const uint32_t next_ip = ip + (skip++ >> 5);
-                    if (next_ip > limit) {          // :342-343, before touching the table
-                        out_of_input = true;
-                        break;
-                    }
-                    const uint32_t nxt = uld32(blk + next_ip);
-                    cand = uni((uint32_t)table[h]);
-                    if (lane == 0) table[h] = (uint16_t)ip;
-                    __builtin_amdgcn_wave_barrier();
-                    if (cur == uld32(blk + cand)) break;
-                    ip = next_ip;
-                    cur = nxt;
-                }
-                if (out_of_input) break;
-
-                // ---- step 2: literal run [next_emit, ip) (:355) ----
-                op = emit_literal(dst, op, blk + next_emit, ip - next_emit, lane);
-
-                // ---- step 3: copy chain (:370-398) ----
-                bool again;
-                bool done = false;
-                uint32_t tail = 0;     // le32(ip+1) after the chain, for the next scan
-                do {
-                    const uint32_t base = ip;
-                    const uint32_t matched = 4 + match_extend(blk, cand + 4, ip + 4, n, lane);
-                    ip += matched;
-                    op = emit_copy(dst, op, base - cand, matched, lane);
-                    next_emit = ip;
-                    if (ip >= limit) {              // :388-389
-                        done = true;
-                        break;
-                    }
-                    const uint64_t w = uld64(blk + ip - 1);          // bytes ip-1 .. ip+6
-                    const uint32_t prev_bytes = (uint32_t)w;
-                    const uint32_t here = (uint32_t)(w >> 8);
-                    tail = (uint32_t)(w >> 16);
-                    const uint32_t hp = (prev_bytes * kHashMul) >> shift;
-                    const uint32_t hc = (here * kHashMul) >> shift;
-                    if (lane == 0) table[hp] = (uint16_t)(ip - 1);   // :391-392
-                    __builtin_amdgcn_wave_barrier();
-                    cand = uni((uint32_t)table[hc]);                 // :394-395
-                    if (lane == 0) table[hc] = (uint16_t)ip;         // :397
-                    __builtin_amdgcn_wave_barrier();
-                    again = (here == uld32(blk + cand));             // :396,:398
-                } while (again);
-                if (done) break;
-
-                ++ip;                                                // :400-401
-                cur = tail;
-            }
-        }
-
-        // emit_remainder (:405-410) and the size prefix (:412)
-        if (next_emit < n) op = emit_literal(dst, op, blk + next_emit, n - next_emit, lane);
-        if (lane == 0) {
-            st32(dst, op - 4);
-            block_bytes[b] = op;
-        }
-        __syncthreads();   // table is re-cleared by the next iteration
     }
 }
 

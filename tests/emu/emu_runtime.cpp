@@ -182,7 +182,7 @@ void launch(uint32_t grid, uint32_t block, const std::function<void()>& body)
 extern "C" {
 
 // Runs compress_blocks_kernel + scan + gather on the CPU emulator.  Returns stream length.
-uint64_t emu_compress(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_t* stream, uint64_t stream_cap)
+uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_t* stream, uint64_t stream_cap, int variant)
 {
     const uint64_t need = 4ull + 32ull + block_size + block_size / 6;
     const uint32_t stride = (uint32_t)((need + 15) & ~15ull);
@@ -197,7 +197,12 @@ uint64_t emu_compress(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_
     if (n) memcpy(inbuf.data(), in, n);
     if (nb)
         emu::launch(nb, 64, [&] {
-            snappy_hip::compress_blocks_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb);
+            if (variant == 2)
+                snappy_hip::compress_blocks_kernel<2>(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb);
+            else if (variant == 1)
+                snappy_hip::compress_blocks_kernel<1>(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb);
+            else
+                snappy_hip::compress_blocks_kernel<0>(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb);
         });
     emu::launch(1, 1024, [&] {
         snappy_hip::scan_block_bytes_kernel(bytes.data(), nb, (uint32_t)n, block_size, stream, offsets.data(), &stream_len);
@@ -207,6 +212,11 @@ uint64_t emu_compress(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_
             snappy_hip::gather_slots_kernel(slots.data(), stride, bytes.data(), offsets.data(), stream, nb);
         });
     return stream_len;
+}
+
+uint64_t emu_compress(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_t* stream, uint64_t stream_cap)
+{
+    return emu_compress_variant(in, n, block_size, stream, stream_cap, 0);
 }
 
 // Runs index_streams_kernel + decompress_blocks_kernel on the emulator.

@@ -27,6 +27,9 @@ def lib():
         L = ctypes.CDLL(build())
         L.emu_compress.restype = ctypes.c_uint64
         L.emu_compress.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64]
+        L.emu_compress_variant.restype = ctypes.c_uint64
+        L.emu_compress_variant.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
+                                           ctypes.c_int]
         L.emu_decompress.restype = ctypes.c_int
         L.emu_decompress.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                      ctypes.c_void_p]
@@ -34,14 +37,14 @@ def lib():
     return _LIB
 
 
-def compress(data, block_size=32768):
+def compress(data, block_size=32768, variant=0):
     a = np.frombuffer(data, dtype=np.uint8).copy() if len(data) else np.zeros(1, dtype=np.uint8)
     n = len(data)
     nb = (n + block_size - 1) // block_size
     stride = (4 + 32 + block_size + block_size // 6 + 15) & ~15
     cap = 10 + nb * stride
     out = np.zeros(cap + 16, dtype=np.uint8)
-    got = lib().emu_compress(a.ctypes.data, n, block_size, out.ctypes.data, cap)
+    got = lib().emu_compress_variant(a.ctypes.data, n, block_size, out.ctypes.data, cap, variant)
     assert got > 0
     return out[:got].tobytes()
 
