@@ -138,10 +138,16 @@ uint32_t snappy_hip_parse_header(const uint8_t *src, uint64_t avail, uint32_t *t
  * snappy_compress.c:284-413).  Block b's u32 size prefix + elements go to
  * d_slots + b*slot_stride; d_block_bytes[b] = 4 + compressed size.
  * d_in must be 16-byte aligned.  `stream` is a hipStream_t (NULL = default stream).
+ *
+ * d_scratch: 256-byte aligned device workspace of snappy_hip_compress_scratch_bytes() bytes (one 32 KiB
+ * hash table per resident wavefront + a work counter; contents need not be initialised, the buffer must
+ * not be shared by launches that run concurrently).  If NULL or too small the LDS-table kernel is used
+ * instead (lower occupancy, same bytes).
  */
+uint64_t snappy_hip_compress_scratch_bytes(void);
 int snappy_hip_compress_blocks(const uint8_t *d_in, uint64_t input_len, uint32_t block_size,
                                uint8_t *d_slots, uint32_t slot_stride, uint32_t *d_block_bytes,
-                               void *stream);
+                               void *d_scratch, uint64_t scratch_bytes, void *stream);
 
 /*
  * Exclusive scan of d_block_bytes + gather of the slots into the contiguous framed stream

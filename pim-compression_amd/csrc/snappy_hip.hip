@@ -94,7 +94,9 @@ int for_each_device(int count, const std::function<int(int)>& fn)
     return 0;
 }
 
-constexpr int kDefaultCompressVariant = snappy_hip::kVariantGlobalScalar;
+constexpr int kDefaultCompressVariant = snappy_hip::kVariantGlobalTable;
+constexpr int kDefaultDecompressVariant = 1;
+constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 
 int env_int(const char* name, int fallback)
 {
@@ -173,8 +175,15 @@ uint32_t snappy_hip_parse_header(const uint8_t* src, uint64_t avail, uint32_t* t
     return a + b;
 }
 
+uint64_t snappy_hip_compress_scratch_bytes(void)
+{
+    // 256-byte header (work counter) + one 32 KiB hash table per resident wavefront (256 CUs x 32 waves)
+    return 256 + (uint64_t)kGlobalTableWaves * snappy_hip::kMaxTableEntries * sizeof(uint16_t);
+}
+
 int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t block_size, uint8_t* d_slots,
-                               uint32_t slot_stride, uint32_t* d_block_bytes, void* stream)
+                               uint32_t slot_stride, uint32_t* d_block_bytes, void* d_scratch, uint64_t scratch_bytes,
+                               void* stream)
 {
     if (!block_size_ok(block_size)) return fail(SNAPPY_HIP_ERR_ARG, "block_size must be 1..65535");
     if (input_len > 0xffffffffull) return fail(SNAPPY_HIP_ERR_ARG, "container length must fit uint32 (snappy_compress.c:461)");
@@ -183,13 +192,38 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
     const uint64_t nb = snappy_hip_num_blocks(input_len, block_size);
     if (nb == 0) return SNAPPY_HIP_OK;
     if (!d_in || !d_slots || !d_block_bytes) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
-    // Tuning knobs (experiments / ablations): SNAPPY_HIP_COMPRESS_VARIANT = 0 global-vector, 1 global-scalar,
-    // 2 LDS-staged input; SNAPPY_HIP_EXTRA_LDS = extra dynamic LDS bytes per workgroup (lowers occupancy).
-    const int variant = env_int("SNAPPY_HIP_COMPRESS_VARIANT", kDefaultCompressVariant);
+    // Tuning knobs (experiments / ablations): SNAPPY_HIP_COMPRESS_VARIANT = 0 LDS table + vector loads,
+    // 1 LDS table + scalar-cache loads, 2 LDS table + LDS-staged input, 3 global-scratch tables at 32 waves/CU
+    // (default), 4 lane-per-block; SNAPPY_HIP_EXTRA_LDS = extra dynamic LDS bytes per workgroup.
+    int variant = env_int("SNAPPY_HIP_COMPRESS_VARIANT", kDefaultCompressVariant);
+    if (variant == snappy_hip::kVariantGlobalTable &&
+        (!d_scratch || scratch_bytes < snappy_hip_compress_scratch_bytes() || ((uintptr_t)d_scratch & 255)))
+        variant = snappy_hip::kVariantGlobalScalar;   // no scratch: LDS-table kernel (still on the GPU)
     uint32_t lds = (uint32_t)env_int("SNAPPY_HIP_EXTRA_LDS", 0);
     const dim3 grid((uint32_t)nb), block(64);
     hipStream_t st = (hipStream_t)stream;
-    if (variant == snappy_hip::kVariantLdsInput) {
+    if (variant == snappy_hip::kVariantLanePerBlock) {
+        static thread_local uint16_t* lane_tables = nullptr;
+        static thread_local uint64_t lane_tables_blocks = 0;
+        if (lane_tables_blocks < nb) {
+            if (lane_tables) (void)hipFree(lane_tables);
+            lane_tables = nullptr;
+            HIP_TRY(hipMalloc((void**)&lane_tables, (size_t)nb * snappy_hip::kMaxTableEntries * sizeof(uint16_t)));
+            lane_tables_blocks = nb;
+        }
+        hipLaunchKernelGGL(snappy_hip::compress_blocks_lane_kernel, dim3((uint32_t)((nb + 63) / 64)), block, 0, st, d_in,
+                           input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, lane_tables);
+    } else if (variant == snappy_hip::kVariantGlobalTable) {
+        // hash tables in the caller's global scratch, persistent grid, blocks handed out by an atomic counter
+        uint32_t waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", kGlobalTableWaves);
+        if (waves > kGlobalTableWaves) waves = kGlobalTableWaves;
+        uint32_t* counter = static_cast<uint32_t*>(d_scratch);
+        uint16_t* tables = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(d_scratch) + 256);
+        HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
+        const uint32_t g = (uint32_t)std::min<uint64_t>(nb, waves);
+        hipLaunchKernelGGL(snappy_hip::compress_blocks_global_table_kernel, dim3(g), block, 0, st, d_in, input_len, block_size,
+                           d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);
+    } else if (variant == snappy_hip::kVariantLdsInput) {
         lds += ((block_size + 15u) & ~15u) + 16u;
         hipLaunchKernelGGL(snappy_hip::compress_blocks_kernel<snappy_hip::kVariantLdsInput>, grid, block, lds, st, d_in,
                            input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb);
@@ -241,9 +275,15 @@ int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, c
     if (!d_stream || !d_block_offsets || !d_out || !d_status) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
     const uint64_t nb = snappy_hip_num_blocks(total_len, block_size);
     if (nb > 0x7fffffffull) return fail(SNAPPY_HIP_ERR_ARG, "too many blocks");
-    const uint32_t lds = (block_size + 15u) & ~15u;
-    hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel, dim3((uint32_t)nb), dim3(64), lds, (hipStream_t)stream, d_stream,
-                       stream_len, d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb);
+    // SNAPPY_HIP_DECOMPRESS_VARIANT: 0 = output window in LDS, 1 = output window in global memory (default)
+    if (env_int("SNAPPY_HIP_DECOMPRESS_VARIANT", kDefaultDecompressVariant) == 0) {
+        const uint32_t lds = (block_size + 15u) & ~15u;
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3((uint32_t)nb), dim3(64), lds, (hipStream_t)stream,
+                           d_stream, stream_len, d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb);
+    } else {
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<false>, dim3((uint32_t)nb), dim3(64), 0, (hipStream_t)stream,
+                           d_stream, stream_len, d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb);
+    }
     HIP_TRY(hipGetLastError());
     return SNAPPY_HIP_OK;
 }
@@ -260,6 +300,7 @@ struct CompressShard {
     uint8_t *d_in = nullptr, *d_slots = nullptr, *d_stream = nullptr;
     uint32_t* d_bytes = nullptr;
     uint64_t *d_offsets = nullptr, *d_stream_len = nullptr;
+    void* d_scratch = nullptr;
     uint64_t stream_len = 0;
     uint32_t local_hdr = 0;
     uint64_t out_off = 0;
@@ -337,6 +378,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
         HIP_TRY(hipMalloc((void**)&s.d_offsets, (s.num_blocks + 1) * sizeof(uint64_t)));
         HIP_TRY(hipMalloc((void**)&s.d_stream_len, sizeof(uint64_t)));
         HIP_TRY(hipMalloc((void**)&s.d_stream, snappy_hip_stream_bound(s.in_len, block_size)));
+        HIP_TRY(hipMalloc(&s.d_scratch, snappy_hip_compress_scratch_bytes()));
         return 0;
     });
     runtime->d_alloc = now_seconds() - t0;
@@ -347,7 +389,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     rc = for_each_device(gpus, [&](int g) -> int {
         HIP_TRY(hipSetDevice(g));
         hipFuncAttributes fa;
-        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_kernel<kDefaultCompressVariant>)));
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel)));
         HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::gather_slots_kernel)));
         return 0;
     });
@@ -375,7 +417,8 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, nullptr));
-        int r = snappy_hip_compress_blocks(s.d_in, s.in_len, block_size, s.d_slots, stride, s.d_bytes, nullptr);
+        int r = snappy_hip_compress_blocks(s.d_in, s.in_len, block_size, s.d_slots, stride, s.d_bytes, s.d_scratch,
+                                           snappy_hip_compress_scratch_bytes(), nullptr);
         if (r) return r;
         r = snappy_hip_compact(s.d_slots, stride, s.d_bytes, s.in_len, block_size, s.d_stream, s.d_offsets, s.d_stream_len, nullptr);
         if (r) return r;
@@ -441,6 +484,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
         (void)hipFree(s.d_bytes);
         (void)hipFree(s.d_offsets);
         (void)hipFree(s.d_stream_len);
+        (void)hipFree(s.d_scratch);
         (void)hipFree(s.d_stream);
         return 0;
     });
@@ -533,7 +577,7 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
     rc = for_each_device(gpus, [&](int g) -> int {
         HIP_TRY(hipSetDevice(g));
         hipFuncAttributes fa;
-        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel)));
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel<false>)));
         return 0;
     });
     runtime->load = now_seconds() - t0;

@@ -24,6 +24,14 @@ constexpr uint32_t kMaxTableEntries = 16384;   // snappy_compress.c:16-17
 constexpr uint32_t kHashMul = 0x1e35a7bdu;     // snappy_compress.c:163
 constexpr uint32_t kInputMargin = 15;          // snappy_compress.c:299
 
+// Keeps a value's computation where it is written (stops LICM from hoisting a use of an in-flight load
+// out of a loop, which would drag its s_waitcnt along).  No code is generated.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SNAPPY_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define SNAPPY_PIN(x) ((void)0)
+#endif
+
 constexpr uint32_t kBlockOk = 0;
 constexpr uint32_t kBlockInvalid = 1;
 
@@ -317,7 +325,7 @@ __device__ __forceinline__ void compress_one_block(Input& in, const uint8_t* __r
     __syncthreads();   // table (and the staged block) are rewritten by the next iteration
 }
 
-enum CompressVariant { kVariantGlobalVector = 0, kVariantGlobalScalar = 1, kVariantLdsInput = 2 };
+enum CompressVariant { kVariantGlobalVector = 0, kVariantGlobalScalar = 1, kVariantLdsInput = 2, kVariantGlobalTable = 3, kVariantLanePerBlock = 4 };
 
 template <int kVariant>
 __global__ __launch_bounds__(64) void compress_blocks_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
@@ -346,6 +354,167 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(const uint8_t* __re
             compress_one_block(src, blk, n, dst, table, stage_buf, lane, block_bytes + b);
         }
     }
+}
+
+// Experimental: no LDS at all.  Hash tables live in a global scratch (32 KiB per resident wavefront, hot in
+// L2 / Infinity Cache), so occupancy is bounded by registers (32 waves/CU) instead of LDS (4-5 waves/CU).
+// Persistent grid; blocks are handed out by an atomic counter (*next_block must be zeroed per launch).
+__global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
+                                                                          uint32_t block_size, uint8_t* __restrict__ slots,
+                                                                          uint32_t slot_stride,
+                                                                          uint32_t* __restrict__ block_bytes,
+                                                                          uint32_t num_blocks, uint16_t* table_scratch,
+                                                                          uint32_t* next_block)
+{
+    const uint32_t lane = threadIdx.x;
+    uint16_t* table = table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
+    for (;;) {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(next_block, 1u);
+        b = uni(b);
+        if (b >= num_blocks) break;
+        const uint64_t start = (uint64_t)b * block_size;
+        const uint64_t left = in_len - start;
+        const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
+        const uint8_t* __restrict__ blk = in + start;
+        uint8_t* __restrict__ dst = slots + (uint64_t)b * slot_stride;
+        InputGlobalScalar src{blk, in, start};
+        compress_one_block(src, blk, n, dst, table, nullptr, lane, block_bytes + b);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1, lane-per-block form: every LANE owns one Snappy block (64 blocks per wavefront) and runs the
+// sequential parse as ordinary SIMT code -- all VALU, no wave-uniform scalar chain, so one
+// wave-instruction advances up to 64 parses.  Each lane's u16 hash table (<= 32 KiB) lives in a global
+// scratch; the dependent table -> candidate loads are hidden by the other resident waves.
+// Same bytes as compress_one_block (snappy_compress.c:284-413).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_emit_literal(uint8_t* __restrict__ dst, uint32_t op,
+                                                      const uint8_t* __restrict__ src, uint32_t len)
+{
+    const uint32_t n = len - 1;                                  // snappy_compress.c:202-225
+    if (n < 60) {
+        dst[op++] = (uint8_t)(n << 2);
+    } else if (n < 256) {
+        dst[op++] = (uint8_t)(60 << 2);
+        dst[op++] = (uint8_t)n;
+    } else if (n < 65536) {
+        dst[op++] = (uint8_t)(61 << 2);
+        dst[op++] = (uint8_t)n;
+        dst[op++] = (uint8_t)(n >> 8);
+    } else {
+        dst[op++] = (uint8_t)(62 << 2);
+        dst[op++] = (uint8_t)n;
+        dst[op++] = (uint8_t)(n >> 8);
+        dst[op++] = (uint8_t)(n >> 16);
+    }
+    uint32_t i = 0;
+    for (; i + 4 <= len; i += 4) st32(dst + op + i, ld32(src + i));
+    for (; i < len; ++i) dst[op + i] = src[i];
+    return op + len;
+}
+
+__device__ __forceinline__ uint32_t lane_emit_copy(uint8_t* __restrict__ dst, uint32_t op, uint32_t off, uint32_t len)
+{
+    for (;;) {                                                   // snappy_compress.c:234-272
+        uint32_t piece = len;
+        if (len >= 68) piece = 64;
+        else if (len > 64) piece = 60;
+        if (piece < 12 && off < 2048) {
+            dst[op++] = (uint8_t)(1 + ((piece - 4) << 2) + ((off >> 8) << 5));
+            dst[op++] = (uint8_t)off;
+        } else {
+            dst[op++] = (uint8_t)(2 + ((piece - 1) << 2));
+            dst[op++] = (uint8_t)off;
+            dst[op++] = (uint8_t)(off >> 8);
+        }
+        len -= piece;
+        if (len == 0) return op;
+    }
+}
+
+__global__ __launch_bounds__(64) void compress_blocks_lane_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
+                                                                  uint32_t block_size, uint8_t* __restrict__ slots,
+                                                                  uint32_t slot_stride, uint32_t* __restrict__ block_bytes,
+                                                                  uint32_t num_blocks, uint16_t* __restrict__ tables)
+{
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= num_blocks) return;
+    const uint64_t start = (uint64_t)b * block_size;
+    const uint64_t left = in_len - start;
+    const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
+    const uint8_t* __restrict__ blk = in + start;
+    uint8_t* __restrict__ dst = slots + (uint64_t)b * slot_stride;
+    uint16_t* __restrict__ table = tables + (size_t)b * kMaxTableEntries;
+
+    const uint32_t ts = table_entries_for(n);                    // snappy_compress.c:139-146
+    const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;      // :288
+    {
+        uint4* t = reinterpret_cast<uint4*>(table);
+        for (uint32_t i = 0; i < ts / 8; ++i) t[i] = make_uint4(0, 0, 0, 0);
+    }
+    uint32_t op = 4, next_emit = 0;
+    if (n >= kInputMargin) {
+        const uint32_t limit = n - kInputMargin;
+        uint32_t ip = 1;
+        uint32_t cur = ld32(blk + ip);
+        for (;;) {
+            uint32_t skip = 32, cand;
+            bool out_of_input = false;
+            for (;;) {                                           // :336-348
+                const uint32_t h = (cur * kHashMul) >> shift;
+                const uint32_t next_ip = ip + (skip++ >> 5);
+                if (next_ip > limit) {
+                    out_of_input = true;
+                    break;
+                }
+                const uint32_t nxt = ld32(blk + next_ip);
+                cand = table[h];
+                table[h] = (uint16_t)ip;
+                if (cur == ld32(blk + cand)) break;
+                ip = next_ip;
+                cur = nxt;
+            }
+            if (out_of_input) break;
+            op = lane_emit_literal(dst, op, blk + next_emit, ip - next_emit);   // :355
+            bool done = false;
+            uint32_t tail = 0;
+            for (;;) {                                           // :370-398
+                const uint32_t base = ip;
+                uint32_t a = cand + 4;
+                ip += 4;
+                while (ip + 4 <= n && ld32(blk + ip) == ld32(blk + a)) {        // :176-193
+                    ip += 4;
+                    a += 4;
+                }
+                while (ip < n && blk[ip] == blk[a]) {
+                    ++ip;
+                    ++a;
+                }
+                op = lane_emit_copy(dst, op, base - cand, ip - base);
+                next_emit = ip;
+                if (ip >= limit) {
+                    done = true;
+                    break;
+                }
+                const uint64_t w = ld64(blk + ip - 1);
+                const uint32_t here = (uint32_t)(w >> 8);
+                tail = (uint32_t)(w >> 16);
+                table[((uint32_t)w * kHashMul) >> shift] = (uint16_t)(ip - 1);
+                const uint32_t hc = (here * kHashMul) >> shift;
+                cand = table[hc];
+                table[hc] = (uint16_t)ip;
+                if (here != ld32(blk + cand)) break;
+            }
+            if (done) break;
+            ++ip;
+            cur = tail;
+        }
+    }
+    if (next_emit < n) op = lane_emit_literal(dst, op, blk + next_emit, n - next_emit);   // :405-410
+    st32(dst, op - 4);                                           // :412
+    block_bytes[b] = op;
 }
 
 // ---------------------------------------------------------------------------
@@ -467,8 +636,18 @@ __global__ __launch_bounds__(64) void index_streams_kernel(const StreamDesc* __r
 }
 
 // ---------------------------------------------------------------------------
-// K2: decompress.  One wavefront per block; the decoded block is staged in LDS so that
-// back-references are LDS reads, then written out with coalesced stores.
+// K2: decompress.  One wavefront per block.
+//
+//  * The compressed stream is consumed through a 128-byte register window: lane l holds the 8 bytes at
+//    compressed offset g+l (W0) and g+64+l (W1); W1 is the prefetch for the next 64 bytes.
+//  * Every lane pre-decodes "the element that would start at my byte" (type, header size, output length,
+//    offset) -- 64 candidate starts per window in a handful of VALU instructions.  The real element chain
+//    is then followed with v_readlane only: no memory access to parse a tag.
+//  * Literal payloads are stored to the LDS output window straight from the window registers (lane l's
+//    byte 0 IS compressed byte g+l); back-references are LDS->LDS replications (`lane % offset` by
+//    reciprocal multiply); the finished block leaves LDS with coalesced 16 B/lane stores.
+//
+// Semantics: snappy_decompress.c:232-285 on well-formed streams, strict otherwise (per-block status).
 // ---------------------------------------------------------------------------
 
 // floor(x / d) for x < 64, 1 <= d < 64:  (x * kRecip16[d]) >> 16  with kRecip16[d] = 65536/d + 1
@@ -478,120 +657,202 @@ __constant__ uint32_t kRecip16[64] = {
      2049,  1986,  1928,  1873,  1821,  1772,  1725,  1681,  1639,  1599,  1561,  1525,  1490,  1457,  1425,  1395,
      1366,  1338,  1311,  1286,  1261,  1237,  1214,  1192,  1171,  1150,  1130,  1111,  1093,  1075,  1058,  1041};
 
-// safe uniform load of up to 8 bytes at stream[ip..], zero-filled past `end`
-__device__ __forceinline__ uint64_t uld64_clamped(const uint8_t* __restrict__ s, uint64_t ip, uint64_t end)
+// Window loads: lane value = the 8 bytes at src[pos..pos+8), zero-filled at and beyond `avail`.
+// Split in two so that a prefetch can stay in flight: window_issue() only issues the (clamped-address)
+// load, window_value() applies the tail shift at the point of use.  For avail >= 8 (wave-uniform test)
+// this is branch-free per lane; streams shorter than 8 bytes take a byte-wise path.
+struct WindowLoad {
+    uint64_t raw;
+    uint32_t shift;   // bits; >= 64 means "all zero"
+};
+__device__ __forceinline__ WindowLoad window_issue(const uint8_t* __restrict__ src, uint64_t pos, uint64_t avail)
 {
-    if (ip + 8 <= end) return uld64(s + ip);
-    uint64_t v = 0;
-    for (uint32_t k = 0; k < 8 && ip + k < end; ++k) v |= (uint64_t)s[ip + k] << (8 * k);
-    return (uint64_t)uni((uint32_t)v) | ((uint64_t)uni((uint32_t)(v >> 32)) << 32);
+    WindowLoad r;
+    if (avail >= 8) {
+        const uint64_t last = avail - 8;
+        const uint64_t a = (pos < last) ? pos : last;
+        r.raw = ld64(src + a);
+        const uint64_t sh = 8 * (pos - a);
+        r.shift = (sh < 64) ? (uint32_t)sh : 64u;
+    } else {
+        r.raw = 0;
+        r.shift = 0;
+        for (uint32_t k = 0; k < 8; ++k)
+            if (pos + k < avail) r.raw |= (uint64_t)src[pos + k] << (8 * k);
+    }
+    return r;
+}
+__device__ __forceinline__ uint64_t window_value(const WindowLoad& r) { return (r.shift < 64) ? (r.raw >> r.shift) : 0; }
+
+// Pre-decode the element that would start with the 8 bytes `w` at compressed offset `pos` of a block of
+// `csz` compressed bytes (snappy_decompress.c:242-284 field rules), branch-free.
+//   meta = type | hdr << 2 | out_len << 8 ; meta == 0 marks an element that cannot be valid here
+//   (over-long literal, header or literal payload running past the block's compressed size).
+//   off  = copy offset (0 for literals).
+__device__ __forceinline__ void predecode(uint64_t w, uint32_t pos, uint32_t csz, uint32_t& meta, uint32_t& off)
+{
+    const uint32_t tag = (uint32_t)w & 0xff;
+    const uint32_t type = tag & 3;
+    const uint32_t v = tag >> 2;
+    const uint32_t next4 = (uint32_t)(w >> 8);
+    // literal (:244-256, :64-74)
+    const uint32_t nb = (v >= 60) ? v - 59 : 0;                              // extra length bytes
+    const uint32_t raw = next4 & (uint32_t)((1ull << (8 * nb)) - 1);
+    const uint32_t lit_len = (v < 60) ? v + 1 : ((raw < 65536u) ? raw + 1 : 0);   // blocks are < 64 KiB
+    // copies (:264-283, :83-133)
+    const uint32_t c1_off = ((tag >> 5) << 8) | (next4 & 0xff);
+    const uint32_t hdr = (type == 0) ? 1 + nb : ((type == 3) ? 5u : type + 1);
+    const uint32_t olen = (type == 0) ? lit_len : ((type == 1) ? (v & 7) + 4 : v + 1);
+    off = (type == 0) ? 0u : ((type == 1) ? c1_off : ((type == 2) ? (next4 & 0xffff) : next4));
+    const uint32_t consumed = hdr + ((type == 0) ? olen : 0);
+    const bool ok = (olen != 0) && (pos + consumed <= csz);
+    meta = ok ? (type | (hdr << 2) | (olen << 8)) : 0;
 }
 
+// kLdsWindow = true : the decoded block is staged in LDS (block_size bytes, ~4 blocks/CU) and written out at the end.
+// kLdsWindow = false: the decoded block is written straight to its place in global memory and back-references
+//   are read from there (vector memory operations of one wavefront complete in issue order on gfx9-family
+//   hardware, so a load issued after a store to the same bytes observes it); no LDS, 32 waves/CU.
+template <bool kLdsWindow>
 __global__ __launch_bounds__(64) void decompress_blocks_kernel(const uint8_t* __restrict__ stream, uint64_t stream_len,
                                                                const uint64_t* __restrict__ block_offsets,
-                                                               uint64_t total_len, uint32_t block_size,
-                                                               uint8_t* __restrict__ out, uint32_t* __restrict__ status,
-                                                               uint32_t num_blocks)
+                                                               uint64_t total_len, uint32_t block_size, uint8_t* out,
+                                                               uint32_t* __restrict__ status, uint32_t num_blocks)
 {
-    HIP_DYNAMIC_SHARED(uint8_t, win)   // block_size rounded up to 16; dynamic LDS starts 16-byte aligned
+    HIP_DYNAMIC_SHARED(uint8_t, lds_win)   // kLdsWindow: block_size rounded up to 16; dynamic LDS starts 16-byte aligned
     const uint32_t lane = threadIdx.x;
 
     for (uint32_t b = blockIdx.x; b < num_blocks; b += gridDim.x) {
         const uint64_t ostart = (uint64_t)b * block_size;
         const uint64_t oleft = total_len - ostart;
         const uint32_t out_len = (oleft < block_size) ? (uint32_t)oleft : block_size;
-        uint8_t* __restrict__ dst = out + ostart;
+        uint8_t* dst = out + ostart;
+        uint8_t* win = kLdsWindow ? lds_win : dst;
 
         uint32_t st = kBlockOk;
-        uint32_t op = 0;
         const uint64_t at = block_offsets[b];
-        uint64_t ip = at + 4, end = ip;
+        uint32_t csz = 0;
         if (at + 4 > stream_len) {
             st = kBlockInvalid;
         } else {
-            end = ip + (uint64_t)uld32(stream + at);           // snappy_decompress.c:229-230
-            if (end > stream_len) st = kBlockInvalid;
+            csz = uld32(stream + at);                                    // snappy_decompress.c:229-230
+            if (at + 4 + (uint64_t)csz > stream_len) st = kBlockInvalid;
         }
+        const uint8_t* __restrict__ src = stream + at + 4;
+        const uint64_t avail = (st == kBlockOk) ? stream_len - (at + 4) : 0;
 
-        while (st == kBlockOk && ip < end) {                    // :232
-            const uint64_t w = uld64_clamped(stream, ip, end);  // tag + up to 7 following bytes
-            const uint32_t tag = (uint32_t)w & 0xff;
-            const uint32_t type = tag & 3;
-            if (type == 0) {                                    // literal, :244-256
-                uint32_t len = (tag >> 2) + 1, hdr = 1;
-                if (len > 60) {                                 // :64-74
-                    const uint32_t nb = len - 60;
-                    hdr = 1 + nb;
-                    len = ((uint32_t)(w >> 8) & (0xffffffffu >> (32 - 8 * nb))) + 1;
-                }
-                if (ip + hdr + len > end || op + len > out_len || len == 0) {
+        uint32_t g = 0;             // window base, multiple of 64 (compressed offset)
+        uint32_t cp = 0, op = 0;    // compressed / output cursors
+        uint64_t w0 = 0;
+        WindowLoad next = {0, 64};  // prefetch of the following 64 bytes (W1), shift applied at use
+        bool have_window = false;
+        // Pending back-reference batch: up to 64 output bytes of consecutive copy elements whose sources are
+        // already final.  Lane k of the batch copies win[bsrc] -> win[bdst]; one LDS round trip per flush.
+        uint32_t bsrc = 0, bdst = 0;     // per lane
+        uint32_t bfill = 0;              // lanes in use (wave-uniform)
+        uint32_t bfirst = 0;             // output position of the first byte of the batch
+
+#define SNAPPY_FLUSH_COPIES()                                   \
+    do {                                                        \
+        if (bfill) {                                            \
+            uint8_t v_ = 0;                                     \
+            if (lane < bfill) v_ = win[bsrc];                   \
+            __builtin_amdgcn_wave_barrier();                    \
+            if (lane < bfill) win[bdst] = v_;                   \
+            __builtin_amdgcn_wave_barrier();                    \
+            bfill = 0;                                          \
+        }                                                       \
+    } while (0)
+
+        while (st == kBlockOk && cp < csz) {                             // one iteration per 64-byte window
+            if (!have_window || cp >= g + 128) {
+                g = cp & ~63u;
+                w0 = window_value(window_issue(src, (uint64_t)g + lane, avail));
+                have_window = true;
+            } else {                                                     // cp in [g+64, g+128): slide by 64
+                g += 64;
+                w0 = window_value(next);
+            }
+            uint32_t meta, offv;
+            predecode(w0, g + lane, csz, meta, offv);
+            // issue the prefetch only after w0 has been consumed, so the wait for w0 cannot cover it
+            __builtin_amdgcn_sched_barrier(0);
+            next = window_issue(src, (uint64_t)g + 64 + lane, avail);    // stays in flight during this window
+            const uint32_t wend = (csz < g + 64) ? csz : g + 64;
+
+            while (cp < wend) {                                          // :232, elements that start in this window
+                const uint32_t s = cp - g;                               // lane that holds this element's tag
+                const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)meta, (int)s);
+                const uint32_t type = m & 3, hdr = (m >> 2) & 7, len = m >> 8;
+                if (m == 0 || op + len > out_len) {                      // m == 0: rejected by predecode
                     st = kBlockInvalid;
                     break;
                 }
-                if (hdr + len <= 8) {
-                    // payload already sits in w
-                    if (lane < len) win[op + lane] = (uint8_t)(w >> (8 * (hdr + lane)));
-                } else if (len <= kWave) {
-                    if (lane < len) win[op + lane] = stream[ip + hdr + lane];
-                } else {
-                    const uint8_t* __restrict__ src = stream + ip + hdr;
-                    uint32_t i = 4 * lane;
-                    for (; i + 4 <= len; i += 4 * kWave) st32(win + op + i, ld32(src + i));
-                    for (; i < len; ++i) win[op + i] = src[i];
+                if (type == 0) {                                         // literal, :244-256
+                    // Literal bytes land at >= op, pending copies only read < their own op <= op: no flush needed.
+                    const uint32_t rel = s + hdr;                        // payload start relative to g
+                    if (rel + len <= 128) {
+                        // payload bytes are byte 0 of window lanes rel .. rel+len-1
+                        if (lane >= rel && lane < rel + len) win[op + lane - rel] = (uint8_t)w0;
+                        if (rel + len > 64) {                            // spills into W1 (wave-uniform)
+                            WindowLoad nx = next;
+                            SNAPPY_PIN(nx.shift);                        // first use of the prefetch: wait here, not earlier
+                            const uint64_t w1 = window_value(nx);
+                            if (lane + 64 >= rel && lane + 64 < rel + len) win[op + lane + 64 - rel] = (uint8_t)w1;
+                        }
+                    } else {
+                        const uint8_t* __restrict__ p = src + cp + hdr;  // long literal: straight from memory
+                        uint32_t i = 4 * lane;
+                        for (; i + 4 <= len; i += 4 * kWave) st32(win + op + i, ld32(p + i));
+                        for (; i < len; ++i) win[op + i] = p[i];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    cp += hdr + len;
+                    op += len;
+                    continue;
                 }
-                __builtin_amdgcn_wave_barrier();
-                ip += hdr + len;
+                const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)s);
+                // strict: the source must lie inside this block's own output (cf. :167-173)
+                if (off == 0 || off > op) {
+                    st = kBlockInvalid;
+                    break;
+                }
+                // :174-181 forward byte copy == periodic replication of the last `off` bytes.
+                // Source bytes are [op-off, op-off+min(len,off)); they must not be pending in the batch.
+                const uint32_t span = (len < off) ? len : off;
+                if (bfill + len > kWave || (bfill && op - off + span > bfirst)) SNAPPY_FLUSH_COPIES();
+                if (bfill == 0) bfirst = op;
+                {
+                    const uint32_t idx = lane - bfill;                   // wraps for lanes below bfill
+                    uint32_t src_idx = idx;
+                    if (off < len) {                                     // overlap: idx % off (idx < 64, off < 64)
+                        const uint32_t q = ((idx & 63) * kRecip16[off]) >> 16;
+                        src_idx = idx - q * off;
+                    }
+                    const bool mine = idx < len;
+                    bsrc = mine ? (op - off + src_idx) : bsrc;
+                    bdst = mine ? (op + idx) : bdst;
+                }
+                bfill += len;
+                cp += hdr;
                 op += len;
-                continue;
             }
-            uint32_t len, off, hdr;
-            if (type == 1) {                                    // :264-266, :83-88
-                len = ((tag >> 2) & 7) + 4;
-                off = ((tag >> 5) << 8) | ((uint32_t)(w >> 8) & 0xff);
-                hdr = 2;
-            } else if (type == 2) {                             // :271-273, :97-109
-                len = (tag >> 2) + 1;
-                off = (uint32_t)(w >> 8) & 0xffff;
-                hdr = 3;
-            } else {                                            // :278-280, :118-133
-                len = (tag >> 2) + 1;
-                off = (uint32_t)(w >> 8);
-                hdr = 5;
-            }
-            // strict: source must lie inside this block's own output (cf. :167-173)
-            if (ip + hdr > end || off == 0 || off > op || op + len > out_len) {
-                st = kBlockInvalid;
-                break;
-            }
-            // :174-181 forward byte copy == periodic replication of the last `off` bytes
-            {
-                uint32_t src_idx = lane;
-                if (off < len) {                                // overlap: lane % off
-                    const uint32_t q = (lane * kRecip16[off]) >> 16;
-                    src_idx = lane - q * off;
-                }
-                uint8_t v = 0;
-                if (lane < len) v = win[op - off + src_idx];
-                __builtin_amdgcn_wave_barrier();
-                if (lane < len) win[op + lane] = v;
-                __builtin_amdgcn_wave_barrier();
-            }
-            ip += hdr;
-            op += len;
         }
-        if (st == kBlockOk && (op != out_len || ip != end)) st = kBlockInvalid;
+        SNAPPY_FLUSH_COPIES();
+#undef SNAPPY_FLUSH_COPIES
+        if (st == kBlockOk && (op != out_len || cp != csz)) st = kBlockInvalid;
 
         // write-out: LDS -> global, 16 B per lane when the destination allows it
         __syncthreads();
-        if (st == kBlockOk) {
+        if (kLdsWindow && st == kBlockOk) {
             if ((((uintptr_t)dst) & 15) == 0) {
                 const uint32_t body = out_len & ~15u;
-                const uint4* __restrict__ w4 = reinterpret_cast<const uint4*>(win);
+                const uint4* __restrict__ w4 = reinterpret_cast<const uint4*>(lds_win);
                 uint4* __restrict__ d4 = reinterpret_cast<uint4*>(dst);
                 for (uint32_t i = lane; i < body / 16; i += kWave) d4[i] = w4[i];
-                for (uint32_t i = body + lane; i < out_len; i += kWave) dst[i] = win[i];
+                for (uint32_t i = body + lane; i < out_len; i += kWave) dst[i] = lds_win[i];
             } else {
-                for (uint32_t i = lane; i < out_len; i += kWave) dst[i] = win[i];
+                for (uint32_t i = lane; i < out_len; i += kWave) dst[i] = lds_win[i];
             }
         }
         if (lane == 0) status[b] = st;

@@ -69,7 +69,8 @@ def lib():
         L.snappy_hip_parse_header.restype = u32
         L.snappy_hip_parse_header.argtypes = [vp, u64, ctypes.POINTER(u32), ctypes.POINTER(u32)]
         L.snappy_hip_compress_blocks.restype = ctypes.c_int
-        L.snappy_hip_compress_blocks.argtypes = [vp, u64, u32, vp, u32, vp, vp]
+        L.snappy_hip_compress_blocks.argtypes = [vp, u64, u32, vp, u32, vp, vp, u64, vp]
+        L.snappy_hip_compress_scratch_bytes.restype = u64
         L.snappy_hip_compact.restype = ctypes.c_int
         L.snappy_hip_compact.argtypes = [vp, u32, vp, u64, u32, vp, vp, vp, vp]
         L.snappy_hip_index_streams.restype = ctypes.c_int
@@ -145,6 +146,9 @@ class CompressWorkspace:
         self.block_bytes = torch.empty(max(nb, 1), dtype=torch.int32, device=device)
         self.offsets = torch.empty(nb + 1, dtype=torch.int64, device=device)
         self.stream_len = torch.zeros(1, dtype=torch.int64, device=device)
+        self.scratch_bytes = int(lib().snappy_hip_compress_scratch_bytes())
+        self.scratch = torch.empty(self.scratch_bytes + 256, dtype=torch.uint8, device=device)
+        self.scratch_ptr = (self.scratch.data_ptr() + 255) & ~255
 
     def stream_capacity(self, n):
         return int(lib().snappy_hip_stream_bound(n, self.block_size))
@@ -154,7 +158,8 @@ def compress_blocks(d_in, n, ws):
     """K1 only: per-block compress into ws.slots / ws.block_bytes (async on the current stream)."""
     import torch
     _check(lib().snappy_hip_compress_blocks(d_in.data_ptr(), n, ws.block_size, ws.slots.data_ptr(), ws.stride,
-                                            ws.block_bytes.data_ptr(), _stream_handle(torch)), "snappy_hip_compress_blocks")
+                                            ws.block_bytes.data_ptr(), ws.scratch_ptr, ws.scratch_bytes,
+                                            _stream_handle(torch)), "snappy_hip_compress_blocks")
 
 
 def compact(n, ws, d_stream):

@@ -195,9 +195,13 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
     // padded copy so the same (unaligned, slightly over-reading) loads stay inside the allocation
     std::vector<uint8_t> inbuf(n + 64, 0x55);
     if (n) memcpy(inbuf.data(), in, n);
+    std::vector<uint16_t> lane_tables(variant == 4 ? (size_t)nb * 16384 : 1);
     if (nb)
         emu::launch(nb, 64, [&] {
-            if (variant == 2)
+            if (variant == 4) {
+                if (emu::bidx().x * 64 < nb)
+                    snappy_hip::compress_blocks_lane_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, lane_tables.data());
+            } else if (variant == 2)
                 snappy_hip::compress_blocks_kernel<2>(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb);
             else if (variant == 1)
                 snappy_hip::compress_blocks_kernel<1>(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb);
@@ -221,8 +225,8 @@ uint64_t emu_compress(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_
 
 // Runs index_streams_kernel + decompress_blocks_kernel on the emulator.
 // Returns 0 on success, 1 if any block (or the chain) is invalid.
-int emu_decompress(const uint8_t* stream, uint64_t stream_len, uint32_t total_len, uint32_t block_size, uint32_t header_len,
-                   uint8_t* out)
+int emu_decompress_variant(const uint8_t* stream, uint64_t stream_len, uint32_t total_len, uint32_t block_size,
+                           uint32_t header_len, uint8_t* out, int variant)
 {
     const uint32_t nb = block_size ? (uint32_t)(((uint64_t)total_len + block_size - 1) / block_size) : 0;
     if (nb == 0) return stream_len == header_len ? 0 : 1;
@@ -233,10 +237,19 @@ int emu_decompress(const uint8_t* stream, uint64_t stream_len, uint32_t total_le
     if (result[0] != 0 || result[1] != nb) return 1;
     std::vector<uint32_t> status(nb, 9);
     emu::launch(nb, 64, [&] {
-        snappy_hip::decompress_blocks_kernel(stream, stream_len, boff.data(), total_len, block_size, out, status.data(), nb);
+        if (variant == 0)
+            snappy_hip::decompress_blocks_kernel<true>(stream, stream_len, boff.data(), total_len, block_size, out, status.data(), nb);
+        else
+            snappy_hip::decompress_blocks_kernel<false>(stream, stream_len, boff.data(), total_len, block_size, out, status.data(), nb);
     });
     for (uint32_t i = 0; i < nb; ++i)
         if (status[i] != 0) return 1;
     return 0;
+}
+
+int emu_decompress(const uint8_t* stream, uint64_t stream_len, uint32_t total_len, uint32_t block_size, uint32_t header_len,
+                   uint8_t* out)
+{
+    return emu_decompress_variant(stream, stream_len, total_len, block_size, header_len, out, 1);
 }
 }

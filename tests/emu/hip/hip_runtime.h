@@ -50,3 +50,12 @@ void syncthreads(int site);
 #define __ballot(p) ((unsigned long long)emu::collective(emu::OP_BALLOT, (uint64_t)((p) ? 1 : 0), 0, __LINE__))
 #define __shfl_up(v, d) ((int)emu::collective(emu::OP_SHFL_UP, (uint64_t)(uint32_t)(v), (uint32_t)(d), __LINE__))
 #define __syncthreads() emu::syncthreads(__LINE__)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+
+// single-threaded fibers: a plain read-modify-write is atomic
+static inline uint32_t atomicAdd(uint32_t* p, uint32_t v)
+{
+    const uint32_t old = *p;
+    *p = old + v;
+    return old;
+}

@@ -33,6 +33,9 @@ def lib():
         L.emu_decompress.restype = ctypes.c_int
         L.emu_decompress.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                      ctypes.c_void_p]
+        L.emu_decompress_variant.restype = ctypes.c_int
+        L.emu_decompress_variant.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                             ctypes.c_void_p, ctypes.c_int]
         _LIB = L
     return _LIB
 
@@ -49,8 +52,8 @@ def compress(data, block_size=32768, variant=0):
     return out[:got].tobytes()
 
 
-def decompress(stream, total_len, block_size, header_len):
+def decompress(stream, total_len, block_size, header_len, variant=1):
     a = np.frombuffer(stream, dtype=np.uint8).copy()
     out = np.zeros(max(total_len, 1) + 16, dtype=np.uint8)
-    st = lib().emu_decompress(a.ctypes.data, a.size, total_len, block_size, header_len, out.ctypes.data)
+    st = lib().emu_decompress_variant(a.ctypes.data, a.size, total_len, block_size, header_len, out.ctypes.data, variant)
     return st, out[:total_len].tobytes()

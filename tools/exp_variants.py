@@ -60,15 +60,19 @@ def main():
     boff = ws.offsets[:nb].contiguous()
     status = torch.empty(nb, dtype=torch.int32, device="cuda")
     out = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
-    times = []
-    for it in range(4):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        shb.decompress_blocks(d_stream, slen, boff, n, 32768, out, status)
-        e1.record()
-        torch.cuda.synchronize()
-        times.append(e0.elapsed_time(e1))
-    print(f"decompress best {min(times[1:]):8.3f} ms {n / min(times[1:]) / 1e6:8.2f} GB/s ok={torch.equal(out[:n], d_in[:n])}")
+    for dv in ("0", "1"):
+        os.environ["SNAPPY_HIP_DECOMPRESS_VARIANT"] = dv
+        out.zero_()
+        times = []
+        for it in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            shb.decompress_blocks(d_stream, slen, boff, n, 32768, out, status)
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1))
+        print(f"decompress variant {dv} best {min(times[1:]):8.3f} ms {n / min(times[1:]) / 1e6:8.2f} GB/s "
+              f"ok={torch.equal(out[:n], d_in[:n])} bad_blocks={int((status != 0).sum())}")
 
 
 if __name__ == "__main__":
