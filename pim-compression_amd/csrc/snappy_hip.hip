@@ -96,6 +96,7 @@ int for_each_device(int count, const std::function<int(int)>& fn)
 
 constexpr int kDefaultCompressVariant = snappy_hip::kVariantGlobalTable;
 constexpr int kDefaultDecompressVariant = 1;
+constexpr int kDefaultK1Tune = 5;
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 
 int env_int(const char* name, int fallback)
@@ -221,8 +222,21 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
         uint16_t* tables = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(d_scratch) + 256);
         HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
         const uint32_t g = (uint32_t)std::min<uint64_t>(nb, waves);
-        hipLaunchKernelGGL(snappy_hip::compress_blocks_global_table_kernel, dim3(g), block, 0, st, d_in, input_len, block_size,
-                           d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);
+        switch (env_int("SNAPPY_HIP_K1_TUNE", kDefaultK1Tune)) {
+#define SNAPPY_LAUNCH_K1(T)                                                                                                   \
+    case T:                                                                                                                   \
+        hipLaunchKernelGGL(snappy_hip::compress_blocks_global_table_kernel<T>, dim3(g), block, 0, st, d_in, input_len,      \
+                           block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);                  \
+        break;
+            SNAPPY_LAUNCH_K1(0)
+            SNAPPY_LAUNCH_K1(1)
+            SNAPPY_LAUNCH_K1(2)
+            SNAPPY_LAUNCH_K1(4)
+            SNAPPY_LAUNCH_K1(5)
+            default:
+            SNAPPY_LAUNCH_K1(3)
+#undef SNAPPY_LAUNCH_K1
+        }
     } else if (variant == snappy_hip::kVariantLdsInput) {
         lds += ((block_size + 15u) & ~15u) + 16u;
         hipLaunchKernelGGL(snappy_hip::compress_blocks_kernel<snappy_hip::kVariantLdsInput>, grid, block, lds, st, d_in,
@@ -389,7 +403,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     rc = for_each_device(gpus, [&](int g) -> int {
         HIP_TRY(hipSetDevice(g));
         hipFuncAttributes fa;
-        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel)));
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel<kDefaultK1Tune>)));
         HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::gather_slots_kernel)));
         return 0;
     });

@@ -356,9 +356,267 @@ __global__ __launch_bounds__(64) void compress_blocks_kernel(const uint8_t* __re
     }
 }
 
-// Experimental: no LDS at all.  Hash tables live in a global scratch (32 KiB per resident wavefront, hot in
-// L2 / Infinity Cache), so occupancy is bounded by registers (32 waves/CU) instead of LDS (4-5 waves/CU).
-// Persistent grid; blocks are handed out by an atomic counter (*next_block must be zeroed per launch).
+// ---------------------------------------------------------------------------
+// K1, windowed form (default).  Same parse as compress_one_block, restructured around what the
+// PMC profile showed to be the limits of the wave-uniform design: scalar-ALU issue (one scalar unit
+// per CU) and serialized memory round trips per probe.
+//
+//  * Cursor side: a sliding register window.  Lane l holds x = le32(block + base + l) and its hash for
+//    the 64 positions of the current 64-byte granule, plus a prefetch of the next granule.  The bytes
+//    and the hash of the position being probed are one v_readlane each -- no load, no address math,
+//    no multiply on the scalar unit.
+//  * Candidate side: one 16-byte scalar load returns the 4 bytes for the hit test AND the next 8 bytes
+//    for the match extension, so a match of up to 12 bytes costs no further round trip; longer matches
+//    continue in the 64-lane extender.
+//  * Hash tables: one u16[16384] per resident wavefront in a global scratch (hot in L2 / Infinity
+//    Cache) so occupancy is bounded by registers (32 waves/CU), not LDS.  Persistent grid; blocks are
+//    handed out by an atomic counter (*next_block zeroed per launch).
+// Bit-exactness: identical decisions to snappy_compress.c:284-413; only where bytes are read from differs.
+// ---------------------------------------------------------------------------
+struct CursorWindow {
+    const uint8_t* __restrict__ blk;   // block start
+    uint32_t avail;                    // readable bytes from blk (clamped to 2^31)
+    uint32_t shift;                    // hash shift of this block
+    uint32_t base;                     // window base (multiple of 64)
+    uint32_t x0, h0;                   // per lane: le32(blk + base + l), its hash
+    uint32_t x1;                       // per lane: le32(blk + base + 64 + l) -- prefetch, possibly in flight
+
+    __device__ __forceinline__ uint32_t load_at(uint32_t pos, uint32_t lane) const
+    {
+        const uint32_t q = pos + lane;
+        const uint32_t last = avail - 4;                         // avail >= 15 whenever the window is used
+        return ld32(blk + ((q < last) ? q : last));              // lanes past the end read a clamped address
+    }
+    __device__ __forceinline__ void reset(uint32_t pos, uint32_t lane)
+    {
+        base = pos & ~63u;
+        x0 = load_at(base, lane);
+        h0 = (x0 * kHashMul) >> shift;
+        __builtin_amdgcn_sched_barrier(0);
+        x1 = load_at(base + 64, lane);
+    }
+    // make `pos` fall inside [base, base + 64)
+    __device__ __forceinline__ void ensure(uint32_t pos, uint32_t lane)
+    {
+        if (pos < base + 64) return;
+        if (pos < base + 128) {
+            base += 64;
+            x0 = x1;
+            h0 = (x0 * kHashMul) >> shift;
+            __builtin_amdgcn_sched_barrier(0);
+            x1 = load_at(base + 64, lane);
+        } else {
+            reset(pos, lane);
+        }
+    }
+    __device__ __forceinline__ uint32_t bytes_at(uint32_t pos) const   // pos in [base, base+64)
+    {
+        return (uint32_t)__builtin_amdgcn_readlane((int)x0, (int)(pos - base));
+    }
+    __device__ __forceinline__ uint32_t hash_at(uint32_t pos) const
+    {
+        return (uint32_t)__builtin_amdgcn_readlane((int)h0, (int)(pos - base));
+    }
+    // le32 at pos for pos in [base, base+128): second granule forces the wait on the prefetch
+    __device__ __forceinline__ uint32_t bytes_near(uint32_t pos) const
+    {
+        const uint32_t rel = pos - base;
+        if (rel < 64) return (uint32_t)__builtin_amdgcn_readlane((int)x0, (int)rel);
+        uint32_t v = x1;
+        SNAPPY_PIN(v);
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(rel - 64));
+    }
+};
+
+// Candidate bytes through the scalar cache.  `blk4` is the block start rounded down to 4 bytes, `mis` the
+// 0..3 bytes that were rounded away; one s_load_dwordx4 (SGPR offset) fetches 16 aligned bytes that cover
+// cand .. cand+12.  first4() is the hit test; next8() is only evaluated on a hit (match extension).
+// Needs cand + 16 <= block length (true for every candidate: cand < ip <= n - 15).
+struct CandidateBytes {
+    uint32_t w0, w1, w2, w3, sh;
+    __device__ __forceinline__ void fetch(const uint32_t* __restrict__ blk4, uint32_t mis, uint32_t cand)
+    {
+        const uint32_t t = cand + mis;
+        struct Quad {
+            uint32_t a, b, c, d;
+        } q;
+        __builtin_memcpy(&q, blk4 + (t >> 2), sizeof(q));        // one s_load_dwordx4
+        w0 = q.a;
+        w1 = q.b;
+        w2 = q.c;
+        w3 = q.d;
+        sh = (t & 3) << 3;
+    }
+    // same bytes, addressed from the 16-byte aligned container base with a 64-bit position (ablation form)
+    __device__ __forceinline__ void fetch_abs(const uint8_t* __restrict__ base16, uint64_t abs_pos)
+    {
+        const uint32_t* w = static_cast<const uint32_t*>(__builtin_assume_aligned(base16 + (abs_pos & ~3ull), 4));
+        w0 = w[0];
+        w1 = w[1];
+        w2 = w[2];
+        w3 = w[3];
+        sh = 8 * (uint32_t)(abs_pos & 3);
+    }
+    // eager form: all three dwords shifted at fetch time (w0..w2 then hold c0..c2, sh = 0)
+    __device__ __forceinline__ void fetch_abs_eager(const uint8_t* __restrict__ base16, uint64_t abs_pos)
+    {
+        const uint32_t* w = static_cast<const uint32_t*>(__builtin_assume_aligned(base16 + (abs_pos & ~3ull), 4));
+        const uint32_t s8 = 8 * (uint32_t)(abs_pos & 3);
+        const uint64_t v01 = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+        const uint64_t v12 = (uint64_t)w[1] | ((uint64_t)w[2] << 32);
+        const uint64_t v23 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+        w0 = (uint32_t)(v01 >> s8);
+        w1 = (uint32_t)(v12 >> s8);
+        w2 = (uint32_t)(v23 >> s8);
+        w3 = 0xffffffffu;   // marks the eager layout
+        sh = 0;
+    }
+    __device__ __forceinline__ uint32_t first4() const { return (uint32_t)(((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh); }
+    __device__ __forceinline__ uint64_t next8_eager() const { return (uint64_t)w1 | ((uint64_t)w2 << 32); }
+    __device__ __forceinline__ uint64_t next8() const
+    {
+        const uint32_t lo = (uint32_t)(((uint64_t)w1 | ((uint64_t)w2 << 32)) >> sh);
+        const uint32_t hi = (uint32_t)(((uint64_t)w2 | ((uint64_t)w3 << 32)) >> sh);
+        return (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+};
+
+// table[h] read + write (snappy_compress.c:346-347).  The index is pinned into a VGPR so the access uses
+// SGPR-base + VGPR-offset addressing (no 64-bit scalar address arithmetic), and every lane stores the same
+// value to the same address (one write on the wire, no exec-mask save/restore).
+template <bool kAllLanes>
+__device__ __forceinline__ uint32_t table_exchange(uint16_t* __restrict__ table, uint32_t h, uint32_t pos, uint32_t lane)
+{
+    if constexpr (kAllLanes) {
+        uint32_t hv = h;
+        SNAPPY_PIN(hv);
+        const uint32_t old = uni((uint32_t)table[hv]);   // every lane has read before any lane writes
+        table[hv] = (uint16_t)pos;
+        __builtin_amdgcn_wave_barrier();
+        return old;
+    } else {
+        const uint32_t old = uni((uint32_t)table[h]);
+        if (lane == 0) table[h] = (uint16_t)pos;
+        __builtin_amdgcn_wave_barrier();
+        return old;
+    }
+}
+template <bool kAllLanes>
+__device__ __forceinline__ void table_put(uint16_t* __restrict__ table, uint32_t h, uint32_t pos, uint32_t lane)
+{
+    if constexpr (kAllLanes) {
+        uint32_t hv = h;
+        SNAPPY_PIN(hv);
+        table[hv] = (uint16_t)pos;
+    } else {
+        if (lane == 0) table[h] = (uint16_t)pos;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int kTune>   // bit 0: all-lane table store + VGPR index; bit 1: candidate bytes addressed from base16; bit 2: eager shifts
+__device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __restrict__ base16, uint64_t start,
+                                                            uint64_t in_len, uint32_t n, uint8_t* __restrict__ dst,
+                                                            uint16_t* __restrict__ table, uint32_t lane,
+                                                            uint32_t* __restrict__ block_bytes_out)
+{
+    const uint8_t* __restrict__ blk = base16 + start;
+    const uint32_t mis = (uint32_t)(start & 3);
+    const uint32_t* __restrict__ blk4 =
+        static_cast<const uint32_t*>(__builtin_assume_aligned(base16 + (start & ~3ull), 4));
+    // get_hash_table, snappy_compress.c:139-146 (+ shift, :288)
+    const uint32_t ts = table_entries_for(n);
+    const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
+    {
+        uint4* t = reinterpret_cast<uint4*>(table);
+        for (uint32_t i = lane; i < ts / 8; i += kWave) t[i] = make_uint4(0, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t op = 4;          // :291
+    uint32_t next_emit = 0;   // :298
+
+    if (n >= kInputMargin) {  // :301
+        const uint32_t limit = n - kInputMargin;
+        const uint64_t left = in_len - start;
+        CursorWindow win;
+        win.blk = blk;
+        win.avail = (left < 0x7fffffffull) ? (uint32_t)left : 0x7fffffffu;
+        win.shift = shift;
+        win.reset(0, lane);
+        uint32_t ip = 1;      // :305
+        for (;;) {
+            // ---- step 1: scan for a 4-byte match (:333-348) ----
+            uint32_t skip = 32;
+            uint32_t cand = 0;
+            CandidateBytes cb;
+            bool hit = false;
+            for (;;) {
+                win.ensure(ip, lane);
+                const uint32_t cur = win.bytes_at(ip);
+                const uint32_t h = win.hash_at(ip);
+                const uint32_t next_ip = ip + (skip++ >> 5);
+                if (next_ip > limit) break;     // :342-343, before touching the table
+                cand = table_exchange<(kTune & 1) != 0>(table, h, ip, lane);
+                if constexpr ((kTune & 4) != 0) cb.fetch_abs_eager(base16, start + cand);
+                else if constexpr ((kTune & 2) != 0) cb.fetch_abs(base16, start + cand);
+                else cb.fetch(blk4, mis, cand);
+                if (cur == cb.first4()) {
+                    hit = true;
+                    break;
+                }
+                ip = next_ip;
+            }
+            if (!hit) break;
+
+            // ---- step 2: literal run [next_emit, ip) (:355) ----
+            op = emit_literal(dst, op, blk + next_emit, ip - next_emit, lane);
+
+            // ---- step 3: copy chain (:370-398) ----
+            bool done = false;
+            for (;;) {
+                const uint32_t base = ip;
+                // find_match_length (:176-193): first 8 bytes on the scalar side, the rest by 64 lanes
+                const uint64_t mine = (uint64_t)win.bytes_near(ip + 4) | ((uint64_t)win.bytes_near(ip + 8) << 32);
+                const uint64_t diff = mine ^ (((kTune & 4) != 0) ? cb.next8_eager() : cb.next8());
+                uint32_t matched;
+                if (diff) {
+                    matched = 4 + ((uint32_t)__builtin_ctzll(diff) >> 3);
+                } else {
+                    matched = 12 + match_extend(blk, cand + 12, ip + 12, n, lane);
+                }
+                ip += matched;
+                op = emit_copy(dst, op, base - cand, matched, lane);
+                next_emit = ip;
+                if (ip >= limit) {              // :388-389
+                    done = true;
+                    break;
+                }
+                win.ensure(ip - 1, lane);
+                table_put<(kTune & 1) != 0>(table, win.hash_at(ip - 1), ip - 1, lane);   // :391-392
+                win.ensure(ip, lane);
+                const uint32_t here = win.bytes_at(ip);
+                cand = table_exchange<(kTune & 1) != 0>(table, win.hash_at(ip), ip, lane);   // :394-397
+                if constexpr ((kTune & 4) != 0) cb.fetch_abs_eager(base16, start + cand);
+                else if constexpr ((kTune & 2) != 0) cb.fetch_abs(base16, start + cand);
+                else cb.fetch(blk4, mis, cand);
+                if (here != cb.first4()) break;                  // :396,:398
+            }
+            if (done) break;
+            ++ip;                                                // :400-401
+        }
+    }
+
+    // emit_remainder (:405-410) and the size prefix (:412)
+    if (next_emit < n) op = emit_literal(dst, op, blk + next_emit, n - next_emit, lane);
+    if (lane == 0) {
+        st32(dst, op - 4);
+        *block_bytes_out = op;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int kTune>
 __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
                                                                           uint32_t block_size, uint8_t* __restrict__ slots,
                                                                           uint32_t slot_stride,
@@ -367,7 +625,7 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
                                                                           uint32_t* next_block)
 {
     const uint32_t lane = threadIdx.x;
-    uint16_t* table = table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
+    uint16_t* __restrict__ table = table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
     for (;;) {
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(next_block, 1u);
@@ -376,10 +634,7 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
         const uint64_t start = (uint64_t)b * block_size;
         const uint64_t left = in_len - start;
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
-        const uint8_t* __restrict__ blk = in + start;
-        uint8_t* __restrict__ dst = slots + (uint64_t)b * slot_stride;
-        InputGlobalScalar src{blk, in, start};
-        compress_one_block(src, blk, n, dst, table, nullptr, lane, block_bytes + b);
+        compress_one_block_windowed<kTune>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, table, lane, block_bytes + b);
     }
 }
 

@@ -196,7 +196,16 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
     std::vector<uint8_t> inbuf(n + 64, 0x55);
     if (n) memcpy(inbuf.data(), in, n);
     std::vector<uint16_t> lane_tables(variant == 4 ? (size_t)nb * 16384 : 1);
-    if (nb)
+    if (nb && variant == 3) {
+        // persistent kernel: a few workgroups pull blocks from the shared counter
+        const uint32_t grid = nb < 3 ? nb : 3;
+        std::vector<uint16_t> tables((size_t)grid * 16384, 0xBEEF);
+        uint32_t counter = 0;
+        emu::launch(grid, 64, [&] {
+            snappy_hip::compress_blocks_global_table_kernel<5>(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb,
+                                                            tables.data(), &counter);
+        });
+    } else if (nb)
         emu::launch(nb, 64, [&] {
             if (variant == 4) {
                 if (emu::bidx().x * 64 < nb)
@@ -220,7 +229,7 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
 
 uint64_t emu_compress(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_t* stream, uint64_t stream_cap)
 {
-    return emu_compress_variant(in, n, block_size, stream, stream_cap, 0);
+    return emu_compress_variant(in, n, block_size, stream, stream_cap, 3);
 }
 
 // Runs index_streams_kernel + decompress_blocks_kernel on the emulator.
