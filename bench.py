@@ -275,7 +275,7 @@ def main():
             "space_saving": round(1.0 - tot_comp / tot_bytes, 6),
             "compress_kernel_GBps": round(u / (c_ms * 1e-3) / 1e9, 3),
             "decompress_kernel_GBps": round(u / (d_ms * 1e-3) / 1e9, 3),
-            "roofline": {"bound": "hbm", "kernel": "compress_blocks_kernel", "achieved": round(achieved, 3),
+            "roofline": {"bound": "hbm", "kernel": "compress_blocks_global_table_kernel", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
                          "traffic": (pmc or {}).get("compress_blocks_kernel_bytes_per_launch"),
                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(c_ms, 4),

@@ -94,9 +94,8 @@ int for_each_device(int count, const std::function<int(int)>& fn)
     return 0;
 }
 
-constexpr int kDefaultCompressVariant = snappy_hip::kVariantGlobalTable;
+constexpr int kVariantLdsTable = 1, kVariantGlobalTable = 3, kVariantLanePerBlock = 4;
 constexpr int kDefaultDecompressVariant = 1;
-constexpr int kDefaultK1Tune = 5;
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 
 int env_int(const char* name, int fallback)
@@ -193,17 +192,17 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
     const uint64_t nb = snappy_hip_num_blocks(input_len, block_size);
     if (nb == 0) return SNAPPY_HIP_OK;
     if (!d_in || !d_slots || !d_block_bytes) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
-    // Tuning knobs (experiments / ablations): SNAPPY_HIP_COMPRESS_VARIANT = 0 LDS table + vector loads,
-    // 1 LDS table + scalar-cache loads, 2 LDS table + LDS-staged input, 3 global-scratch tables at 32 waves/CU
-    // (default), 4 lane-per-block; SNAPPY_HIP_EXTRA_LDS = extra dynamic LDS bytes per workgroup.
-    int variant = env_int("SNAPPY_HIP_COMPRESS_VARIANT", kDefaultCompressVariant);
-    if (variant == snappy_hip::kVariantGlobalTable &&
+    // SNAPPY_HIP_COMPRESS_VARIANT (ablations): 3 = windowed parse, hash tables in the caller's global scratch,
+    // 32 waves/CU (default); 1 = LDS hash table, 4-5 waves/CU (also the path taken when no scratch is given);
+    // 4 = lane-per-block SIMT experiment.  SNAPPY_HIP_EXTRA_LDS adds dynamic LDS per workgroup (occupancy ablation).
+    int variant = env_int("SNAPPY_HIP_COMPRESS_VARIANT", kVariantGlobalTable);
+    if (variant == kVariantGlobalTable &&
         (!d_scratch || scratch_bytes < snappy_hip_compress_scratch_bytes() || ((uintptr_t)d_scratch & 255)))
-        variant = snappy_hip::kVariantGlobalScalar;   // no scratch: LDS-table kernel (still on the GPU)
-    uint32_t lds = (uint32_t)env_int("SNAPPY_HIP_EXTRA_LDS", 0);
+        variant = kVariantLdsTable;   // no scratch: LDS-table kernel (still on the GPU)
+    const uint32_t lds = (uint32_t)env_int("SNAPPY_HIP_EXTRA_LDS", 0);
     const dim3 grid((uint32_t)nb), block(64);
     hipStream_t st = (hipStream_t)stream;
-    if (variant == snappy_hip::kVariantLanePerBlock) {
+    if (variant == kVariantLanePerBlock) {
         static thread_local uint16_t* lane_tables = nullptr;
         static thread_local uint64_t lane_tables_blocks = 0;
         if (lane_tables_blocks < nb) {
@@ -212,41 +211,22 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
             HIP_TRY(hipMalloc((void**)&lane_tables, (size_t)nb * snappy_hip::kMaxTableEntries * sizeof(uint16_t)));
             lane_tables_blocks = nb;
         }
-        hipLaunchKernelGGL(snappy_hip::compress_blocks_lane_kernel, dim3((uint32_t)((nb + 63) / 64)), block, 0, st, d_in,
-                           input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, lane_tables);
-    } else if (variant == snappy_hip::kVariantGlobalTable) {
-        // hash tables in the caller's global scratch, persistent grid, blocks handed out by an atomic counter
+        const uint32_t rep = (uint32_t)env_int("SNAPPY_HIP_LANES_PER_BLOCK", 1);
+        hipLaunchKernelGGL(snappy_hip::compress_blocks_lane_kernel, dim3((uint32_t)((nb * rep + 63) / 64)), block, 0, st, d_in,
+                           input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, lane_tables, rep);
+    } else if (variant == kVariantLdsTable) {
+        hipLaunchKernelGGL(snappy_hip::compress_blocks_lds_table_kernel, grid, block, lds, st, d_in, input_len, block_size,
+                           d_slots, slot_stride, d_block_bytes, (uint32_t)nb);
+    } else {
+        // persistent grid, blocks handed out by an atomic counter kept in the first bytes of the scratch
         uint32_t waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", kGlobalTableWaves);
         if (waves > kGlobalTableWaves) waves = kGlobalTableWaves;
         uint32_t* counter = static_cast<uint32_t*>(d_scratch);
         uint16_t* tables = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(d_scratch) + 256);
         HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
         const uint32_t g = (uint32_t)std::min<uint64_t>(nb, waves);
-        switch (env_int("SNAPPY_HIP_K1_TUNE", kDefaultK1Tune)) {
-#define SNAPPY_LAUNCH_K1(T)                                                                                                   \
-    case T:                                                                                                                   \
-        hipLaunchKernelGGL(snappy_hip::compress_blocks_global_table_kernel<T>, dim3(g), block, 0, st, d_in, input_len,      \
-                           block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);                  \
-        break;
-            SNAPPY_LAUNCH_K1(0)
-            SNAPPY_LAUNCH_K1(1)
-            SNAPPY_LAUNCH_K1(2)
-            SNAPPY_LAUNCH_K1(4)
-            SNAPPY_LAUNCH_K1(5)
-            default:
-            SNAPPY_LAUNCH_K1(3)
-#undef SNAPPY_LAUNCH_K1
-        }
-    } else if (variant == snappy_hip::kVariantLdsInput) {
-        lds += ((block_size + 15u) & ~15u) + 16u;
-        hipLaunchKernelGGL(snappy_hip::compress_blocks_kernel<snappy_hip::kVariantLdsInput>, grid, block, lds, st, d_in,
-                           input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb);
-    } else if (variant == snappy_hip::kVariantGlobalScalar) {
-        hipLaunchKernelGGL(snappy_hip::compress_blocks_kernel<snappy_hip::kVariantGlobalScalar>, grid, block, lds, st, d_in,
-                           input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb);
-    } else {
-        hipLaunchKernelGGL(snappy_hip::compress_blocks_kernel<snappy_hip::kVariantGlobalVector>, grid, block, lds, st, d_in,
-                           input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb);
+        hipLaunchKernelGGL(snappy_hip::compress_blocks_global_table_kernel, dim3(g), block, 0, st, d_in, input_len, block_size,
+                           d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);
     }
     HIP_TRY(hipGetLastError());
     return SNAPPY_HIP_OK;
@@ -403,7 +383,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     rc = for_each_device(gpus, [&](int g) -> int {
         HIP_TRY(hipSetDevice(g));
         hipFuncAttributes fa;
-        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel<kDefaultK1Tune>)));
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel)));
         HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::gather_slots_kernel)));
         return 0;
     });

@@ -171,22 +171,11 @@ __device__ __forceinline__ uint32_t match_extend(const uint8_t* __restrict__ blk
 }
 
 // ---------------------------------------------------------------------------
-// Input-access policies for K1.  The parse reads the block at (a) the cursor, sequentially, and
-// (b) hash-table candidates, randomly inside [0, cursor).  Where those bytes live decides the
-// latency of every serial step, so the kernel is templated on it.
+// Input access of the LDS-table form of K1 (the fallback used when the caller passes no scratch).
 // ---------------------------------------------------------------------------
 
-// Block read straight from HBM/L2 with vector loads; LDS holds only the hash table (5 blocks/CU).
-struct InputGlobalVector {
-    const uint8_t* __restrict__ blk;
-    __device__ __forceinline__ void stage(const uint8_t* __restrict__ b, uint32_t, uint32_t, uint8_t*) { blk = b; }
-    __device__ __forceinline__ uint32_t u32(uint32_t p) const { return uld32(blk + p); }
-    __device__ __forceinline__ uint64_t u64(uint32_t p) const { return uld64(blk + p); }
-    __device__ __forceinline__ const uint8_t* bytes() const { return blk; }
-};
-
-// Same, but the wave-uniform reads go through the scalar cache (s_load_dwordx2/x4 on aligned dwords +
-// 64-bit shift), which returns into SGPRs directly.  `base16` is the 16-byte aligned container base.
+// Wave-uniform reads through the scalar cache (s_load_dwordx2/x4 on aligned dwords + 64-bit shift),
+// which returns into SGPRs directly.  `base16` is the 16-byte aligned container base.
 struct InputGlobalScalar {
     const uint8_t* __restrict__ blk;
     const uint8_t* __restrict__ base16;
@@ -211,28 +200,8 @@ struct InputGlobalScalar {
     __device__ __forceinline__ const uint8_t* bytes() const { return blk; }
 };
 
-// Block staged into LDS once (coalesced 16 B/lane), every later read is an LDS read.
-// 64 KiB of LDS per 32 KiB block (table + input): 2 blocks/CU, but ~10x lower read latency.
-struct InputLds {
-    const uint8_t* lds;
-    __device__ __forceinline__ void stage(const uint8_t* __restrict__ b, uint32_t n, uint32_t lane, uint8_t* buf)
-    {
-        uint32_t i = 16 * lane;
-        for (; i + 16 <= n; i += 16 * kWave) {
-            uint4 v;
-            __builtin_memcpy(&v, b + i, 16);
-            *reinterpret_cast<uint4*>(buf + i) = v;
-        }
-        for (; i < n; ++i) buf[i] = b[i];     // one lane, < 16 bytes
-        lds = buf;
-    }
-    __device__ __forceinline__ uint32_t u32(uint32_t p) const { return uld32(lds + p); }
-    __device__ __forceinline__ uint64_t u64(uint32_t p) const { return uld64(lds + p); }
-    __device__ __forceinline__ const uint8_t* bytes() const { return lds; }
-};
-
 // ---------------------------------------------------------------------------
-// K1: compress.  One wavefront per block (grid-stride).
+// K1, LDS-table form: one wavefront per block (grid-stride), u16 hash table in LDS (4-5 blocks/CU).
 // ---------------------------------------------------------------------------
 template <class Input>
 __device__ __forceinline__ void compress_one_block(Input& in, const uint8_t* __restrict__ blk_global, uint32_t n,
@@ -325,34 +294,20 @@ __device__ __forceinline__ void compress_one_block(Input& in, const uint8_t* __r
     __syncthreads();   // table (and the staged block) are rewritten by the next iteration
 }
 
-enum CompressVariant { kVariantGlobalVector = 0, kVariantGlobalScalar = 1, kVariantLdsInput = 2, kVariantGlobalTable = 3, kVariantLanePerBlock = 4 };
-
-template <int kVariant>
-__global__ __launch_bounds__(64) void compress_blocks_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
-                                                             uint32_t block_size, uint8_t* __restrict__ slots,
-                                                             uint32_t slot_stride, uint32_t* __restrict__ block_bytes,
-                                                             uint32_t num_blocks)
+__global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
+                                                                       uint32_t block_size, uint8_t* __restrict__ slots,
+                                                                       uint32_t slot_stride,
+                                                                       uint32_t* __restrict__ block_bytes, uint32_t num_blocks)
 {
     __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTableEntries];
-    HIP_DYNAMIC_SHARED(uint8_t, stage_buf)   // kVariantLdsInput: block_size rounded up to 16 (+16); else unused
     const uint32_t lane = threadIdx.x;
-
     for (uint32_t b = blockIdx.x; b < num_blocks; b += gridDim.x) {
         const uint64_t start = (uint64_t)b * block_size;
         const uint64_t left = in_len - start;
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
         const uint8_t* __restrict__ blk = in + start;
-        uint8_t* __restrict__ dst = slots + (uint64_t)b * slot_stride;
-        if constexpr (kVariant == kVariantGlobalScalar) {
-            InputGlobalScalar src{blk, in, start};
-            compress_one_block(src, blk, n, dst, table, stage_buf, lane, block_bytes + b);
-        } else if constexpr (kVariant == kVariantLdsInput) {
-            InputLds src{stage_buf};
-            compress_one_block(src, blk, n, dst, table, stage_buf, lane, block_bytes + b);
-        } else {
-            InputGlobalVector src{blk};
-            compress_one_block(src, blk, n, dst, table, stage_buf, lane, block_bytes + b);
-        }
+        InputGlobalScalar src{blk, in, start};
+        compress_one_block(src, blk, n, slots + (uint64_t)b * slot_stride, table, nullptr, lane, block_bytes + b);
     }
 }
 
@@ -428,102 +383,52 @@ struct CursorWindow {
     }
 };
 
-// Candidate bytes through the scalar cache.  `blk4` is the block start rounded down to 4 bytes, `mis` the
-// 0..3 bytes that were rounded away; one s_load_dwordx4 (SGPR offset) fetches 16 aligned bytes that cover
-// cand .. cand+12.  first4() is the hit test; next8() is only evaluated on a hit (match extension).
-// Needs cand + 16 <= block length (true for every candidate: cand < ip <= n - 15).
+// 12 candidate bytes through the scalar cache: c0 = le32(cand) for the hit test, c1/c2 = the next 8 bytes for
+// the match extension.  Aligned dwords + 64-bit shifts; needs cand + 16 <= block length (true for every
+// candidate: cand < ip <= n - 15).  (Shifting all three eagerly measured 10 % faster than deferring c1/c2.)
 struct CandidateBytes {
-    uint32_t w0, w1, w2, w3, sh;
-    __device__ __forceinline__ void fetch(const uint32_t* __restrict__ blk4, uint32_t mis, uint32_t cand)
-    {
-        const uint32_t t = cand + mis;
-        struct Quad {
-            uint32_t a, b, c, d;
-        } q;
-        __builtin_memcpy(&q, blk4 + (t >> 2), sizeof(q));        // one s_load_dwordx4
-        w0 = q.a;
-        w1 = q.b;
-        w2 = q.c;
-        w3 = q.d;
-        sh = (t & 3) << 3;
-    }
-    // same bytes, addressed from the 16-byte aligned container base with a 64-bit position (ablation form)
-    __device__ __forceinline__ void fetch_abs(const uint8_t* __restrict__ base16, uint64_t abs_pos)
+    uint32_t c0, c1, c2;
+    __device__ __forceinline__ void fetch(const uint8_t* __restrict__ base16, uint64_t abs_pos)
     {
         const uint32_t* w = static_cast<const uint32_t*>(__builtin_assume_aligned(base16 + (abs_pos & ~3ull), 4));
-        w0 = w[0];
-        w1 = w[1];
-        w2 = w[2];
-        w3 = w[3];
-        sh = 8 * (uint32_t)(abs_pos & 3);
-    }
-    // eager form: all three dwords shifted at fetch time (w0..w2 then hold c0..c2, sh = 0)
-    __device__ __forceinline__ void fetch_abs_eager(const uint8_t* __restrict__ base16, uint64_t abs_pos)
-    {
-        const uint32_t* w = static_cast<const uint32_t*>(__builtin_assume_aligned(base16 + (abs_pos & ~3ull), 4));
-        const uint32_t s8 = 8 * (uint32_t)(abs_pos & 3);
+        const uint32_t sh = 8 * (uint32_t)(abs_pos & 3);
         const uint64_t v01 = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
         const uint64_t v12 = (uint64_t)w[1] | ((uint64_t)w[2] << 32);
         const uint64_t v23 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
-        w0 = (uint32_t)(v01 >> s8);
-        w1 = (uint32_t)(v12 >> s8);
-        w2 = (uint32_t)(v23 >> s8);
-        w3 = 0xffffffffu;   // marks the eager layout
-        sh = 0;
+        c0 = (uint32_t)(v01 >> sh);
+        c1 = (uint32_t)(v12 >> sh);
+        c2 = (uint32_t)(v23 >> sh);
     }
-    __device__ __forceinline__ uint32_t first4() const { return (uint32_t)(((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh); }
-    __device__ __forceinline__ uint64_t next8_eager() const { return (uint64_t)w1 | ((uint64_t)w2 << 32); }
-    __device__ __forceinline__ uint64_t next8() const
-    {
-        const uint32_t lo = (uint32_t)(((uint64_t)w1 | ((uint64_t)w2 << 32)) >> sh);
-        const uint32_t hi = (uint32_t)(((uint64_t)w2 | ((uint64_t)w3 << 32)) >> sh);
-        return (uint64_t)lo | ((uint64_t)hi << 32);
-    }
+    __device__ __forceinline__ uint64_t next8() const { return (uint64_t)c1 | ((uint64_t)c2 << 32); }
 };
 
 // table[h] read + write (snappy_compress.c:346-347).  The index is pinned into a VGPR so the access uses
-// SGPR-base + VGPR-offset addressing (no 64-bit scalar address arithmetic), and every lane stores the same
-// value to the same address (one write on the wire, no exec-mask save/restore).
-template <bool kAllLanes>
-__device__ __forceinline__ uint32_t table_exchange(uint16_t* __restrict__ table, uint32_t h, uint32_t pos, uint32_t lane)
+// SGPR-base + VGPR-offset addressing, and every lane stores the same value to the same address (one write on
+// the wire, no exec-mask save/restore).  uni() sits between the load and the store, so every lane has read
+// before any lane writes.
+__device__ __forceinline__ uint32_t table_exchange(uint16_t* __restrict__ table, uint32_t h, uint32_t pos)
 {
-    if constexpr (kAllLanes) {
-        uint32_t hv = h;
-        SNAPPY_PIN(hv);
-        const uint32_t old = uni((uint32_t)table[hv]);   // every lane has read before any lane writes
-        table[hv] = (uint16_t)pos;
-        __builtin_amdgcn_wave_barrier();
-        return old;
-    } else {
-        const uint32_t old = uni((uint32_t)table[h]);
-        if (lane == 0) table[h] = (uint16_t)pos;
-        __builtin_amdgcn_wave_barrier();
-        return old;
-    }
+    uint32_t hv = h;
+    SNAPPY_PIN(hv);
+    const uint32_t old = uni((uint32_t)table[hv]);
+    table[hv] = (uint16_t)pos;
+    __builtin_amdgcn_wave_barrier();
+    return old;
 }
-template <bool kAllLanes>
-__device__ __forceinline__ void table_put(uint16_t* __restrict__ table, uint32_t h, uint32_t pos, uint32_t lane)
+__device__ __forceinline__ void table_put(uint16_t* __restrict__ table, uint32_t h, uint32_t pos)
 {
-    if constexpr (kAllLanes) {
-        uint32_t hv = h;
-        SNAPPY_PIN(hv);
-        table[hv] = (uint16_t)pos;
-    } else {
-        if (lane == 0) table[h] = (uint16_t)pos;
-    }
+    uint32_t hv = h;
+    SNAPPY_PIN(hv);
+    table[hv] = (uint16_t)pos;
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int kTune>   // bit 0: all-lane table store + VGPR index; bit 1: candidate bytes addressed from base16; bit 2: eager shifts
 __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __restrict__ base16, uint64_t start,
                                                             uint64_t in_len, uint32_t n, uint8_t* __restrict__ dst,
                                                             uint16_t* __restrict__ table, uint32_t lane,
                                                             uint32_t* __restrict__ block_bytes_out)
 {
     const uint8_t* __restrict__ blk = base16 + start;
-    const uint32_t mis = (uint32_t)(start & 3);
-    const uint32_t* __restrict__ blk4 =
-        static_cast<const uint32_t*>(__builtin_assume_aligned(base16 + (start & ~3ull), 4));
     // get_hash_table, snappy_compress.c:139-146 (+ shift, :288)
     const uint32_t ts = table_entries_for(n);
     const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
@@ -557,11 +462,9 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
                 const uint32_t h = win.hash_at(ip);
                 const uint32_t next_ip = ip + (skip++ >> 5);
                 if (next_ip > limit) break;     // :342-343, before touching the table
-                cand = table_exchange<(kTune & 1) != 0>(table, h, ip, lane);
-                if constexpr ((kTune & 4) != 0) cb.fetch_abs_eager(base16, start + cand);
-                else if constexpr ((kTune & 2) != 0) cb.fetch_abs(base16, start + cand);
-                else cb.fetch(blk4, mis, cand);
-                if (cur == cb.first4()) {
+                cand = table_exchange(table, h, ip);
+                cb.fetch(base16, start + cand);
+                if (cur == cb.c0) {
                     hit = true;
                     break;
                 }
@@ -578,7 +481,7 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
                 const uint32_t base = ip;
                 // find_match_length (:176-193): first 8 bytes on the scalar side, the rest by 64 lanes
                 const uint64_t mine = (uint64_t)win.bytes_near(ip + 4) | ((uint64_t)win.bytes_near(ip + 8) << 32);
-                const uint64_t diff = mine ^ (((kTune & 4) != 0) ? cb.next8_eager() : cb.next8());
+                const uint64_t diff = mine ^ cb.next8();
                 uint32_t matched;
                 if (diff) {
                     matched = 4 + ((uint32_t)__builtin_ctzll(diff) >> 3);
@@ -593,14 +496,12 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
                     break;
                 }
                 win.ensure(ip - 1, lane);
-                table_put<(kTune & 1) != 0>(table, win.hash_at(ip - 1), ip - 1, lane);   // :391-392
+                table_put(table, win.hash_at(ip - 1), ip - 1);   // :391-392
                 win.ensure(ip, lane);
                 const uint32_t here = win.bytes_at(ip);
-                cand = table_exchange<(kTune & 1) != 0>(table, win.hash_at(ip), ip, lane);   // :394-397
-                if constexpr ((kTune & 4) != 0) cb.fetch_abs_eager(base16, start + cand);
-                else if constexpr ((kTune & 2) != 0) cb.fetch_abs(base16, start + cand);
-                else cb.fetch(blk4, mis, cand);
-                if (here != cb.first4()) break;                  // :396,:398
+                cand = table_exchange(table, win.hash_at(ip), ip);   // :394-397
+                cb.fetch(base16, start + cand);
+                if (here != cb.c0) break;                  // :396,:398
             }
             if (done) break;
             ++ip;                                                // :400-401
@@ -616,7 +517,6 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int kTune>
 __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
                                                                           uint32_t block_size, uint8_t* __restrict__ slots,
                                                                           uint32_t slot_stride,
@@ -634,7 +534,7 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
         const uint64_t start = (uint64_t)b * block_size;
         const uint64_t left = in_len - start;
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
-        compress_one_block_windowed<kTune>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, table, lane, block_bytes + b);
+        compress_one_block_windowed(in, start, in_len, n, slots + (uint64_t)b * slot_stride, table, lane, block_bytes + b);
     }
 }
 
@@ -692,9 +592,12 @@ __device__ __forceinline__ uint32_t lane_emit_copy(uint8_t* __restrict__ dst, ui
 __global__ __launch_bounds__(64) void compress_blocks_lane_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
                                                                   uint32_t block_size, uint8_t* __restrict__ slots,
                                                                   uint32_t slot_stride, uint32_t* __restrict__ block_bytes,
-                                                                  uint32_t num_blocks, uint16_t* __restrict__ tables)
+                                                                  uint32_t num_blocks, uint16_t* __restrict__ tables,
+                                                                  uint32_t lanes_per_block)
 {
-    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    // lanes_per_block > 1 replicates each block's (identical) work over a lane group: fewer blocks per wave,
+    // same addresses within a group (coalesced), more waves for the same number of blocks.
+    const uint32_t b = (blockIdx.x * 64 + threadIdx.x) / lanes_per_block;
     if (b >= num_blocks) return;
     const uint64_t start = (uint64_t)b * block_size;
     const uint64_t left = in_len - start;

@@ -202,20 +202,16 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
         std::vector<uint16_t> tables((size_t)grid * 16384, 0xBEEF);
         uint32_t counter = 0;
         emu::launch(grid, 64, [&] {
-            snappy_hip::compress_blocks_global_table_kernel<5>(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb,
+            snappy_hip::compress_blocks_global_table_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb,
                                                             tables.data(), &counter);
         });
     } else if (nb)
         emu::launch(nb, 64, [&] {
             if (variant == 4) {
                 if (emu::bidx().x * 64 < nb)
-                    snappy_hip::compress_blocks_lane_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, lane_tables.data());
-            } else if (variant == 2)
-                snappy_hip::compress_blocks_kernel<2>(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb);
-            else if (variant == 1)
-                snappy_hip::compress_blocks_kernel<1>(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb);
-            else
-                snappy_hip::compress_blocks_kernel<0>(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb);
+                    snappy_hip::compress_blocks_lane_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, lane_tables.data(), 1);
+            } else
+                snappy_hip::compress_blocks_lds_table_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb);
         });
     emu::launch(1, 1024, [&] {
         snappy_hip::scan_block_bytes_kernel(bytes.data(), nb, (uint32_t)n, block_size, stream, offsets.data(), &stream_len);

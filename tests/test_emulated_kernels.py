@@ -43,6 +43,21 @@ def test_emulated_long_runs_and_split_copies():
         assert st == 0 and out == data
 
 
+@pytest.mark.parametrize("cv,dv", [(1, 0), (4, 0)])
+def test_emulated_other_variants(cv, dv):
+    """LDS-table / lane-per-block compress and LDS-window decompress produce the same bytes."""
+    text = golden_bytes("plrabn12.txt")
+    cases = [golden_bytes("coding.txt"), datagen.text_random_interleave(text, 40_000), datagen.periodic(9000, 5),
+             datagen.zeros(5000), datagen.random_bytes(20_000)]
+    for data in cases:
+        for bs in (32768, 4097, 65535):
+            ref = oracle.compress(data, bs)
+            assert emu.compress(data, bs, cv) == ref, (cv, bs)
+            total, got_bs, hdr = oracle.read_header(ref)
+            st, out = emu.decompress(ref, total, got_bs, hdr, dv)
+            assert st == 0 and out == data, (dv, bs)
+
+
 def test_emulated_decoder_is_strict():
     # copy reaching before the block start
     body = bytes([0x00, 0x41, (3 << 2) | 2, 9, 0])

@@ -166,6 +166,39 @@ def test_batched_index_matches_scan_offsets(shb):
         assert int(ws.block_bytes[:nb].sum().item()) + int(ws.offsets[0].item()) == slen
 
 
+# ---- every kernel variant produces the same bytes ------------------------------------------------------
+
+@pytest.mark.parametrize("env", [{"SNAPPY_HIP_COMPRESS_VARIANT": "1"}, {"SNAPPY_HIP_COMPRESS_VARIANT": "4"},
+                                 {"SNAPPY_HIP_COMPRESS_VARIANT": "4", "SNAPPY_HIP_LANES_PER_BLOCK": "16"},
+                                 {"SNAPPY_HIP_COMPRESS_VARIANT": "3", "SNAPPY_HIP_GT_WAVES": "7"},
+                                 {"SNAPPY_HIP_DECOMPRESS_VARIANT": "0"}])
+def test_kernel_variants_bit_exact(shb, env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    text = golden_bytes("plrabn12.txt")
+    inputs = [golden_bytes("world192.txt"), datagen.text_random_interleave(text, 200_000), datagen.zeros(100_000),
+              datagen.periodic(70_000, 7), datagen.random_bytes(150_000), datagen.records(120_000)]
+    for data in inputs:
+        for bs in (32768, 65535, 4097, 600):
+            ref = oracle.compress(data, bs, threads=8)
+            assert gpu_compress(shb, data, bs) == ref, (env, bs)
+            st, out = gpu_decompress(shb, ref)
+            assert st == 0 and out == data, (env, bs)
+
+
+def test_compress_without_scratch_uses_lds_table_kernel(shb):
+    import torch
+    data = golden_bytes("world192.txt")
+    d = to_dev(data)
+    ws = shb.CompressWorkspace(len(data), 32768)
+    ws.scratch_ptr, ws.scratch_bytes = 0, 0        # no scratch: the library must still compress on the GPU
+    d_stream = torch.empty(ws.stream_capacity(len(data)) + 16, dtype=torch.uint8, device="cuda")
+    shb.compress_blocks(d, len(data), ws)
+    shb.compact(len(data), ws, d_stream)
+    n = int(ws.stream_len.item())
+    assert bytes(d_stream[:n].cpu().numpy()) == golden_bytes("world192.snappy")
+
+
 # ---- BASELINE.json full size: one 1 GiB Silesia-mix container -----------------------------------------
 
 def test_full_size_container_roundtrip_and_oracle(shb):
