@@ -92,6 +92,8 @@ class Batch:
         self.status = torch.empty(self.nb, dtype=torch.int32, device="cuda")
         self.out = torch.empty(container_len + 16, dtype=torch.uint8, device="cuda")
         self.kernel_events = {"compress": [], "decompress": []}
+        self.side_stream = torch.cuda.Stream()
+        self.index_done = [torch.cuda.Event() for _ in container_ids]
 
     def _timed(self, key, record, fn):
         if not record:
@@ -105,22 +107,32 @@ class Batch:
         self.kernel_events[key].append((e0, e1))
 
     def step(self, record=False):
-        shb = self.shb
-        # ---- compress every container ----
+        shb, torch = self.shb, self.torch
+        main = torch.cuda.current_stream()
+        side = self.side_stream
+        keep = []
+        # ---- compress every container; the size-chain walk of container i (one wavefront, latency-bound)
+        #      runs on a side stream underneath the compression of container i+1 ----
         for i, d_in in enumerate(self.inputs):
             self._timed("compress", record, lambda: shb.compress_blocks(d_in, self.n, self.ws))
             shb.compact(self.n, self.ws, self.streams[i])
             self.stream_lens[i] = int(self.ws.stream_len.item())      # 8-byte D2H; the decoder needs the length
-        # ---- index all streams in one launch, then decompress each ----
-        descs = shb.make_stream_descs([
-            dict(stream=self.streams[i], stream_len=self.stream_lens[i], block_offsets=self.boffs[i],
-                 result=self.results[i], total_len=self.n, block_size=BLOCK_SIZE, header_len=self.hdr,
-                 num_blocks=self.nb) for i in range(self.count)])
-        shb.index_streams(descs, self.count)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                descs = shb.make_stream_descs([
+                    dict(stream=self.streams[i], stream_len=self.stream_lens[i], block_offsets=self.boffs[i],
+                         result=self.results[i], total_len=self.n, block_size=BLOCK_SIZE, header_len=self.hdr,
+                         num_blocks=self.nb)])
+                shb.index_streams(descs, 1)
+                self.index_done[i].record(side)
+            keep.append(descs)
+        # ---- decompress each stream as soon as its index is ready ----
         for i in range(self.count):
+            main.wait_event(self.index_done[i])
             self._timed("decompress", record,
                         lambda: shb.decompress_blocks(self.streams[i], self.stream_lens[i], self.boffs[i], self.n,
                                                       BLOCK_SIZE, self.out, self.status))
+        self._keep = keep
 
     def verify(self):
         """Outside the timed region: every container round-trips bit-exactly and every block decoded OK."""
@@ -211,12 +223,19 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     shb.lib()                                   # fails loudly if libsnappy_hip.so is missing
+    # SNAPPY_BENCH_BACKEND=gloo + SNAPPY_BENCH_SINGLE_DEVICE=1 rehearse the N>1 path on a one-GPU box
+    backend = os.environ.get("SNAPPY_BENCH_BACKEND", "nccl")
+    if os.environ.get("SNAPPY_BENCH_SINGLE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
@@ -232,7 +251,10 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier(device_ids=[local])
+            if backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     fence()
@@ -244,7 +266,8 @@ def main():
 
     local_bytes = args.steps * batch.count * n
     local_comp = args.steps * sum(batch.stream_lens)
-    secs, tot_bytes, tot_comp = reduce_results(elapsed, local_bytes, local_comp, dist, device="cuda")
+    secs, tot_bytes, tot_comp = reduce_results(elapsed, local_bytes, local_comp, dist,
+                                               device="cuda" if backend == "nccl" else "cpu")
 
     if rank == 0:
         c_ms = batch.kernel_ms("compress")

@@ -94,7 +94,7 @@ int for_each_device(int count, const std::function<int(int)>& fn)
     return 0;
 }
 
-constexpr int kVariantLdsTable = 1, kVariantGlobalTable = 3, kVariantLanePerBlock = 4;
+constexpr int kVariantLdsTable = 1, kVariantGlobalTable = 3, kVariantLanePerBlock = 4, kVariantGroup = 5;
 constexpr int kDefaultDecompressVariant = 1;
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 
@@ -194,7 +194,7 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
     if (!d_in || !d_slots || !d_block_bytes) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
     // SNAPPY_HIP_COMPRESS_VARIANT (ablations): 3 = windowed parse, hash tables in the caller's global scratch,
     // 32 waves/CU (default); 1 = LDS hash table, 4-5 waves/CU (also the path taken when no scratch is given);
-    // 4 = lane-per-block SIMT experiment.  SNAPPY_HIP_EXTRA_LDS adds dynamic LDS per workgroup (occupancy ablation).
+    // 4 = lane-per-block SIMT experiment; 5 = four blocks per wavefront (16-lane groups).  SNAPPY_HIP_EXTRA_LDS adds dynamic LDS per workgroup (occupancy ablation).
     int variant = env_int("SNAPPY_HIP_COMPRESS_VARIANT", kVariantGlobalTable);
     if (variant == kVariantGlobalTable &&
         (!d_scratch || scratch_bytes < snappy_hip_compress_scratch_bytes() || ((uintptr_t)d_scratch & 255)))
@@ -202,7 +202,22 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
     const uint32_t lds = (uint32_t)env_int("SNAPPY_HIP_EXTRA_LDS", 0);
     const dim3 grid((uint32_t)nb), block(64);
     hipStream_t st = (hipStream_t)stream;
-    if (variant == kVariantLanePerBlock) {
+    if (variant == kVariantGroup) {
+        // ablation: 4 blocks per wavefront (16-lane groups); its tables are allocated lazily by the library
+        static thread_local uint16_t* group_tables = nullptr;
+        static thread_local uint64_t group_table_slots = 0;
+        const uint32_t waves = (uint32_t)env_int("SNAPPY_HIP_GROUP_WAVES", kGlobalTableWaves);
+        const uint64_t want_groups = std::min<uint64_t>((uint64_t)waves * 4, (nb + 3) / 4 * 4);
+        const uint32_t g = (uint32_t)((want_groups + 3) / 4);
+        if (group_table_slots < (uint64_t)g * 4) {
+            if (group_tables) (void)hipFree(group_tables);
+            group_tables = nullptr;
+            HIP_TRY(hipMalloc((void**)&group_tables, (size_t)g * 4 * snappy_hip::kMaxTableEntries * sizeof(uint16_t)));
+            group_table_slots = (uint64_t)g * 4;
+        }
+        hipLaunchKernelGGL(snappy_hip::compress_blocks_group_kernel, dim3(g), block, 0, st, d_in, input_len, block_size,
+                           d_slots, slot_stride, d_block_bytes, (uint32_t)nb, group_tables);
+    } else if (variant == kVariantLanePerBlock) {
         static thread_local uint16_t* lane_tables = nullptr;
         static thread_local uint64_t lane_tables_blocks = 0;
         if (lane_tables_blocks < nb) {

@@ -676,6 +676,187 @@ __global__ __launch_bounds__(64) void compress_blocks_lane_kernel(const uint8_t*
 }
 
 // ---------------------------------------------------------------------------
+// K1, group form (ablation, SNAPPY_HIP_COMPRESS_VARIANT=5): FOUR blocks per wavefront.  Each 16-lane group owns
+// one block; the parse is a flat state machine executed as predicated VALU code -- every loop iteration performs
+// ONE probe (scan probe or post-copy probe, snappy_compress.c:336-348 / :391-398) for each of the wave's four
+// groups, so one wave-instruction advances four parses and four independent table -> candidate chains are in
+// flight per wave, none of it on the scalar unit.  Group-uniform state is replicated in the group's lanes; the
+// lanes cooperate on table clears, literal payloads and multi-piece copies.  Hash tables: one u16[16384] per
+// group in a global scratch.  Blocks are assigned statically: group slot s handles blocks s, s + S, s + 2S, ...
+// The only wave collective is the loop condition; wave_barrier()s at the top level of the loop body separate
+// the table store -> load -> store phases (free on hardware, where a wave runs in lockstep).
+// Measured: 26.8 GB/s with 32768 groups in flight (5.4 us per iteration: three dependent HBM-random accesses),
+// i.e. not faster than the wave-per-block form; kept as the starting point for the tag-filtered table idea.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kGroupLanes = 16;
+
+__device__ __forceinline__ uint32_t group_emit_literal(uint8_t* dst, uint32_t op, const uint8_t* src, uint32_t len,
+                                                       uint32_t gl)
+{
+    const uint32_t n1 = len - 1;                                 // snappy_compress.c:202-225
+    const uint32_t hdr = (n1 < 60) ? 1u : ((n1 < 256u) ? 2u : ((n1 < 65536u) ? 3u : 4u));
+    if (gl < hdr) {
+        const uint32_t tag = (n1 < 60) ? (n1 << 2) : ((58 + hdr) << 2);
+        dst[op + gl] = (gl == 0) ? (uint8_t)tag : (uint8_t)(n1 >> (8 * (gl - 1)));
+    }
+    for (uint32_t i = gl; i < len; i += kGroupLanes) dst[op + hdr + i] = src[i];
+    return op + hdr + len;
+}
+
+__device__ __forceinline__ uint32_t group_emit_copy(uint8_t* dst, uint32_t op, uint32_t off, uint32_t len, uint32_t gl)
+{
+    if (len > 64) {                                              // snappy_compress.c:254-272
+        const uint32_t n64 = (len >= 68) ? ((len - 68) / 64 + 1) : 0;
+        len -= 64 * n64;
+        const uint32_t has60 = (len > 64) ? 1u : 0u;
+        if (has60) len -= 60;
+        const uint32_t nfull = n64 + has60;
+        for (uint32_t k = gl; k < nfull; k += kGroupLanes) {
+            const uint32_t plen = (k < n64) ? 64u : 60u;
+            uint8_t* p = dst + op + 3 * k;
+            p[0] = (uint8_t)(2 + ((plen - 1) << 2));
+            p[1] = (uint8_t)off;
+            p[2] = (uint8_t)(off >> 8);
+        }
+        op += 3 * nfull;
+    }
+    if (len < 12 && off < 2048) {                                // snappy_compress.c:234-245
+        if (gl < 2) dst[op + gl] = (gl == 0) ? (uint8_t)(1 + ((len - 4) << 2) + ((off >> 8) << 5)) : (uint8_t)off;
+        return op + 2;
+    }
+    if (gl < 3) dst[op + gl] = (gl == 0) ? (uint8_t)(2 + ((len - 1) << 2)) : ((gl == 1) ? (uint8_t)off : (uint8_t)(off >> 8));
+    return op + 3;
+}
+
+__global__ __launch_bounds__(64) void compress_blocks_group_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
+                                                                   uint32_t block_size, uint8_t* __restrict__ slots,
+                                                                   uint32_t slot_stride, uint32_t* __restrict__ block_bytes,
+                                                                   uint32_t num_blocks, uint16_t* tables)
+{
+    enum : uint32_t { kInit = 0, kScan = 1, kCopy = 2, kDone = 3 };
+    const uint32_t lane = threadIdx.x;
+    const uint32_t gl = lane & (kGroupLanes - 1);
+    const uint32_t groups_per_wave = kWave / kGroupLanes;
+    const uint32_t slot = blockIdx.x * groups_per_wave + (lane / kGroupLanes);
+    const uint32_t total_slots = gridDim.x * groups_per_wave;
+    uint16_t* table = tables + (size_t)slot * kMaxTableEntries;
+
+    uint32_t mode = kInit;
+    uint32_t b = slot;                         // next block of this group
+    uint32_t n = 0, limit = 0, shift = 0, ip = 0, skip = 32, next_emit = 0, op = 4, cur_block = 0;
+    const uint8_t* blk = in;
+    uint8_t* dst = slots;
+
+    while (__ballot(mode != kDone)) {
+        // ---------------- block start (get_hash_table, snappy_compress.c:139-146, :288-301) ----------------
+        if (mode == kInit) {
+            if (b >= num_blocks) {
+                mode = kDone;
+            } else {
+                cur_block = b;
+                b += total_slots;
+                const uint64_t start = (uint64_t)cur_block * block_size;
+                const uint64_t left = in_len - start;
+                n = (left < block_size) ? (uint32_t)left : block_size;
+                blk = in + start;
+                dst = slots + (uint64_t)cur_block * slot_stride;
+                const uint32_t ts = table_entries_for(n);
+                shift = (uint32_t)__builtin_clz(ts) + 1;
+                uint4* t = reinterpret_cast<uint4*>(table);
+                for (uint32_t i = gl; i < ts / 8; i += kGroupLanes) t[i] = make_uint4(0, 0, 0, 0);
+                op = 4;
+                next_emit = 0;
+                if (n < kInputMargin) {                          // whole block is one literal (:405-412)
+                    op = group_emit_literal(dst, op, blk, n, gl);
+                    if (gl == 0) {
+                        st32(dst, op - 4);
+                        block_bytes[cur_block] = op;
+                    }
+                } else {
+                    limit = n - kInputMargin;
+                    ip = 1;
+                    skip = 32;
+                    mode = kScan;
+                }
+            }
+        }
+        const bool probing = (mode == kScan) || (mode == kCopy);
+
+        // ---------------- phase A: cursor bytes; post-copy insert of ip-1 (:391-392) ----------------
+        uint32_t cur = 0, h = 0, next_ip = 0;
+        bool exhausted = false;
+        if (probing) {
+            const uint64_t w = ld64(blk + ip - 1);               // bytes ip-1 .. ip+6
+            cur = (uint32_t)(w >> 8);
+            h = (cur * kHashMul) >> shift;
+            if (mode == kCopy) {
+                if (gl == 0) table[((uint32_t)w * kHashMul) >> shift] = (uint16_t)(ip - 1);
+            } else {
+                next_ip = ip + (skip >> 5);                      // :339-343
+                ++skip;
+                exhausted = next_ip > limit;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---------------- phase B: candidate lookup (:346, :395) ----------------
+        const bool lookup = probing && !exhausted;
+        uint32_t cand = 0;
+        if (lookup) cand = table[h];
+        __builtin_amdgcn_wave_barrier();
+        // ---------------- phase C: table update, hit test, emission, state update ----------------
+        if (lookup) {
+            if (gl == 0) table[h] = (uint16_t)ip;                // :347, :397
+            const uint64_t c01 = ld64(blk + cand);               // candidate bytes cand .. cand+7 (cand + 16 <= n)
+            const uint32_t c2 = ld32(blk + cand + 8);
+            if (cur != (uint32_t)c01) {
+                // miss: keep scanning (:348) or fall back from the copy chain to scanning (:398-401)
+                if (mode == kCopy) {
+                    mode = kScan;
+                    skip = 32;
+                    ip += 1;
+                } else {
+                    ip = next_ip;
+                }
+            } else {
+                if (mode == kScan) op = group_emit_literal(dst, op, blk + next_emit, ip - next_emit, gl);   // :355
+                // find_match_length (:176-193): 8 bytes at once, then 8-byte / 1-byte steps
+                const uint64_t theirs = (c01 >> 32) | ((uint64_t)c2 << 32);
+                const uint64_t diff = ld64(blk + ip + 4) ^ theirs;
+                uint32_t matched;
+                if (diff) {
+                    matched = 4 + ((uint32_t)__builtin_ctzll(diff) >> 3);
+                } else {
+                    matched = 12;
+                    while (ip + matched + 8 <= n) {
+                        const uint64_t d = ld64(blk + ip + matched) ^ ld64(blk + cand + matched);
+                        if (d) {
+                            matched += (uint32_t)__builtin_ctzll(d) >> 3;
+                            break;
+                        }
+                        matched += 8;
+                    }
+                    if (ip + matched + 8 > n)
+                        while (ip + matched < n && blk[ip + matched] == blk[cand + matched]) ++matched;
+                }
+                op = group_emit_copy(dst, op, ip - cand, matched, gl);   // :380
+                ip += matched;
+                next_emit = ip;
+                if (ip >= limit) exhausted = true;               // :388-389
+                else mode = kCopy;
+            }
+        }
+        if (probing && exhausted) {                              // emit_remainder (:405-412)
+            if (next_emit < n) op = group_emit_literal(dst, op, blk + next_emit, n - next_emit, gl);
+            if (gl == 0) {
+                st32(dst, op - 4);
+                block_bytes[cur_block] = op;
+            }
+            mode = kInit;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // scan + gather: slots -> contiguous framed stream
 // ---------------------------------------------------------------------------
 

@@ -43,7 +43,7 @@ def test_emulated_long_runs_and_split_copies():
         assert st == 0 and out == data
 
 
-@pytest.mark.parametrize("cv,dv", [(1, 0), (4, 0)])
+@pytest.mark.parametrize("cv,dv", [(1, 0), (4, 0), (5, 1)])
 def test_emulated_other_variants(cv, dv):
     """LDS-table / lane-per-block compress and LDS-window decompress produce the same bytes."""
     text = golden_bytes("plrabn12.txt")

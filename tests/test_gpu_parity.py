@@ -171,6 +171,8 @@ def test_batched_index_matches_scan_offsets(shb):
 @pytest.mark.parametrize("env", [{"SNAPPY_HIP_COMPRESS_VARIANT": "1"}, {"SNAPPY_HIP_COMPRESS_VARIANT": "4"},
                                  {"SNAPPY_HIP_COMPRESS_VARIANT": "4", "SNAPPY_HIP_LANES_PER_BLOCK": "16"},
                                  {"SNAPPY_HIP_COMPRESS_VARIANT": "3", "SNAPPY_HIP_GT_WAVES": "7"},
+                                 {"SNAPPY_HIP_COMPRESS_VARIANT": "5"},
+                                 {"SNAPPY_HIP_COMPRESS_VARIANT": "5", "SNAPPY_HIP_GROUP_WAVES": "3"},
                                  {"SNAPPY_HIP_DECOMPRESS_VARIANT": "0"}])
 def test_kernel_variants_bit_exact(shb, env, monkeypatch):
     for k, v in env.items():
