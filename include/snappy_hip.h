@@ -139,8 +139,8 @@ uint32_t snappy_hip_parse_header(const uint8_t *src, uint64_t avail, uint32_t *t
  * d_slots + b*slot_stride; d_block_bytes[b] = 4 + compressed size.
  * d_in must be 16-byte aligned.  `stream` is a hipStream_t (NULL = default stream).
  *
- * d_scratch: 256-byte aligned device workspace of snappy_hip_compress_scratch_bytes() bytes (one 32 KiB
- * hash table per resident wavefront + a work counter; contents need not be initialised, the buffer must
+ * d_scratch: 256-byte aligned device workspace of snappy_hip_compress_scratch_bytes() bytes (one 64 KiB
+ * tagged hash table per resident wavefront + a work counter; contents need not be initialised, the buffer must
  * not be shared by launches that run concurrently).  If NULL or too small the LDS-table kernel is used
  * instead (lower occupancy, same bytes).
  */

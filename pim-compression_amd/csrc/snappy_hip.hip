@@ -177,8 +177,8 @@ uint32_t snappy_hip_parse_header(const uint8_t* src, uint64_t avail, uint32_t* t
 
 uint64_t snappy_hip_compress_scratch_bytes(void)
 {
-    // 256-byte header (work counter) + one 32 KiB hash table per resident wavefront (256 CUs x 32 waves)
-    return 256 + (uint64_t)kGlobalTableWaves * snappy_hip::kMaxTableEntries * sizeof(uint16_t);
+    // 256-byte header (work counter) + one 64 KiB tagged hash table per resident wavefront (256 CUs x 32 waves)
+    return 256 + (uint64_t)kGlobalTableWaves * snappy_hip::kMaxTableEntries * sizeof(uint32_t);
 }
 
 int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t block_size, uint8_t* d_slots,
@@ -237,7 +237,7 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
         uint32_t waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", kGlobalTableWaves);
         if (waves > kGlobalTableWaves) waves = kGlobalTableWaves;
         uint32_t* counter = static_cast<uint32_t*>(d_scratch);
-        uint16_t* tables = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(d_scratch) + 256);
+        uint32_t* tables = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_scratch) + 256);
         HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
         const uint32_t g = (uint32_t)std::min<uint64_t>(nb, waves);
         hipLaunchKernelGGL(snappy_hip::compress_blocks_global_table_kernel, dim3(g), block, 0, st, d_in, input_len, block_size,

@@ -333,8 +333,17 @@ struct CursorWindow {
     uint32_t avail;                    // readable bytes from blk (clamped to 2^31)
     uint32_t shift;                    // hash shift of this block
     uint32_t base;                     // window base (multiple of 64)
-    uint32_t x0, h0;                   // per lane: le32(blk + base + l), its hash
+    uint32_t x0, h0, e0;               // per lane: le32(blk + base + l), its hash, its content tag << 16
     uint32_t x1;                       // per lane: le32(blk + base + 64 + l) -- prefetch, possibly in flight
+
+    // hash (snappy_compress.c:161-166) = top bits of x * kHashMul; the tag is the 16 bits right below them, so two
+    // different 4-byte values that share a table slot also share a tag only once in 65536 times
+    __device__ __forceinline__ void rehash()
+    {
+        const uint32_t prod = x0 * kHashMul;
+        h0 = prod >> shift;
+        e0 = (prod << (32 - shift)) & 0xffff0000u;
+    }
 
     __device__ __forceinline__ uint32_t load_at(uint32_t pos, uint32_t lane) const
     {
@@ -346,7 +355,7 @@ struct CursorWindow {
     {
         base = pos & ~63u;
         x0 = load_at(base, lane);
-        h0 = (x0 * kHashMul) >> shift;
+        rehash();
         __builtin_amdgcn_sched_barrier(0);
         x1 = load_at(base + 64, lane);
     }
@@ -357,7 +366,7 @@ struct CursorWindow {
         if (pos < base + 128) {
             base += 64;
             x0 = x1;
-            h0 = (x0 * kHashMul) >> shift;
+            rehash();
             __builtin_amdgcn_sched_barrier(0);
             x1 = load_at(base + 64, lane);
         } else {
@@ -371,6 +380,11 @@ struct CursorWindow {
     __device__ __forceinline__ uint32_t hash_at(uint32_t pos) const
     {
         return (uint32_t)__builtin_amdgcn_readlane((int)h0, (int)(pos - base));
+    }
+    // table entry for inserting `pos`: tag << 16 | pos
+    __device__ __forceinline__ uint32_t entry_at(uint32_t pos) const
+    {
+        return (uint32_t)__builtin_amdgcn_readlane((int)e0, (int)(pos - base)) | pos;
     }
     // le32 at pos for pos in [base, base+128): second granule forces the wait on the prefetch
     __device__ __forceinline__ uint32_t bytes_near(uint32_t pos) const
@@ -402,39 +416,90 @@ struct CandidateBytes {
     __device__ __forceinline__ uint64_t next8() const { return (uint64_t)c1 | ((uint64_t)c2 << 32); }
 };
 
-// table[h] read + write (snappy_compress.c:346-347).  The index is pinned into a VGPR so the access uses
-// SGPR-base + VGPR-offset addressing, and every lane stores the same value to the same address (one write on
-// the wire, no exec-mask save/restore).  uni() sits between the load and the store, so every lane has read
-// before any lane writes.
-__device__ __forceinline__ uint32_t table_exchange(uint16_t* __restrict__ table, uint32_t h, uint32_t pos)
+// Tagged hash table of the windowed form: entry = tag << 16 | position (u32), where the tag is a 16-bit function
+// of the 4 bytes at that position.  The positions stored and returned are exactly the reference's
+// (snappy_compress.c:346-347, :392-397); the tag only lets a probe whose candidate has a DIFFERENT tag -- hence
+// different 4 bytes, a certain miss in the reference's compare (:348, :398) -- skip fetching the candidate bytes.
+// An empty slot reads "position 0" in the reference, so tables are initialised with position 0's own entry.
+// The index is pinned into a VGPR so the access uses SGPR-base + VGPR-offset addressing, and every lane stores
+// the same value to the same address (one write on the wire, no exec-mask save/restore).  uni() sits between the
+// load and the store, so every lane has read before any lane writes.
+__device__ __forceinline__ uint32_t table_exchange(uint32_t* __restrict__ table, uint32_t h, uint32_t entry)
 {
     uint32_t hv = h;
     SNAPPY_PIN(hv);
-    const uint32_t old = uni((uint32_t)table[hv]);
-    table[hv] = (uint16_t)pos;
+    const uint32_t old = uni(table[hv]);
+    table[hv] = entry;
     __builtin_amdgcn_wave_barrier();
     return old;
 }
-__device__ __forceinline__ void table_put(uint16_t* __restrict__ table, uint32_t h, uint32_t pos)
+__device__ __forceinline__ void table_put(uint32_t* __restrict__ table, uint32_t h, uint32_t entry)
 {
     uint32_t hv = h;
     SNAPPY_PIN(hv);
-    table[hv] = (uint16_t)pos;
+    table[hv] = entry;
     __builtin_amdgcn_wave_barrier();
+}
+
+// Emitters of the windowed form.  Element headers are packed into one dword and stored by a single lane
+// (the 1-2 bytes past the header are overwritten by whatever is emitted next; every slot has >= 32 bytes of
+// slack, snappy_compress.c:55-60), and literal payloads are stored straight from the cursor window registers
+// (byte 0 of lane l's x0 IS block byte base + l) -- no load, so no round trip on the emission path.
+
+// snappy_compress.c:234-245 (len 4..64) / :254-272
+__device__ __forceinline__ uint32_t emit_copy_packed(uint8_t* __restrict__ dst, uint32_t op, uint32_t off, uint32_t len,
+                                                     uint32_t lane)
+{
+    if (len > 64) return emit_copy(dst, op, off, len, lane);     // multi-piece copies: generic path
+    uint32_t word, bytes;
+    if (len < 12 && off < 2048) {
+        word = (1 + ((len - 4) << 2) + ((off >> 8) << 5)) | ((off & 0xff) << 8);
+        bytes = 2;
+    } else {
+        word = (2 + ((len - 1) << 2)) | (off << 8);
+        bytes = 3;
+    }
+    if (lane == 0) st32(dst + op, word);
+    return op + bytes;
+}
+
+// snappy_compress.c:202-225 with the payload taken from the window when [from, from+len) lies inside it
+__device__ __forceinline__ uint32_t emit_literal_windowed(uint8_t* __restrict__ dst, uint32_t op,
+                                                          const uint8_t* __restrict__ blk, uint32_t from, uint32_t len,
+                                                          uint32_t win_base, uint32_t win_x0, uint32_t lane)
+{
+    if (from < win_base || from + len > win_base + kWave) return emit_literal(dst, op, blk + from, len, lane);
+    const uint32_t n = len - 1;                                  // len <= 64 here, so n < 64
+    uint32_t hdr;
+    if (n < 60) {
+        hdr = 1;
+        if (lane == 0) dst[op] = (uint8_t)(n << 2);
+    } else {
+        hdr = 2;
+        if (lane == 0) {
+            dst[op] = (uint8_t)(60 << 2);
+            dst[op + 1] = (uint8_t)n;
+        }
+    }
+    const uint32_t rel = from - win_base;
+    if (lane >= rel && lane < rel + len) dst[op + hdr + lane - rel] = (uint8_t)win_x0;
+    return op + hdr + len;
 }
 
 __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __restrict__ base16, uint64_t start,
                                                             uint64_t in_len, uint32_t n, uint8_t* __restrict__ dst,
-                                                            uint16_t* __restrict__ table, uint32_t lane,
+                                                            uint32_t* __restrict__ table, uint32_t lane,
                                                             uint32_t* __restrict__ block_bytes_out)
 {
     const uint8_t* __restrict__ blk = base16 + start;
     // get_hash_table, snappy_compress.c:139-146 (+ shift, :288)
     const uint32_t ts = table_entries_for(n);
     const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
-    {
+    if (n >= kInputMargin) {
+        // "empty" = candidate position 0 (:346 on a zeroed table), carrying position 0's tag
+        const uint32_t e_zero = ((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u;
         uint4* t = reinterpret_cast<uint4*>(table);
-        for (uint32_t i = lane; i < ts / 8; i += kWave) t[i] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = lane; i < ts / 4; i += kWave) t[i] = make_uint4(e_zero, e_zero, e_zero, e_zero);
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -462,18 +527,22 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
                 const uint32_t h = win.hash_at(ip);
                 const uint32_t next_ip = ip + (skip++ >> 5);
                 if (next_ip > limit) break;     // :342-343, before touching the table
-                cand = table_exchange(table, h, ip);
-                cb.fetch(base16, start + cand);
-                if (cur == cb.c0) {
-                    hit = true;
-                    break;
+                const uint32_t mine = win.entry_at(ip);
+                const uint32_t old = table_exchange(table, h, mine);
+                cand = old & 0xffffu;
+                if (((old ^ mine) >> 16) == 0) {                 // same tag: only now are the bytes worth fetching
+                    cb.fetch(base16, start + cand);
+                    if (cur == cb.c0) {
+                        hit = true;
+                        break;
+                    }
                 }
                 ip = next_ip;
             }
             if (!hit) break;
 
-            // ---- step 2: literal run [next_emit, ip) (:355) ----
-            op = emit_literal(dst, op, blk + next_emit, ip - next_emit, lane);
+            // ---- step 2: literal run [next_emit, ip) (:355); ip is inside the window ----
+            op = emit_literal_windowed(dst, op, blk, next_emit, ip - next_emit, win.base, win.x0, lane);
 
             // ---- step 3: copy chain (:370-398) ----
             bool done = false;
@@ -489,17 +558,20 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
                     matched = 12 + match_extend(blk, cand + 12, ip + 12, n, lane);
                 }
                 ip += matched;
-                op = emit_copy(dst, op, base - cand, matched, lane);
+                op = emit_copy_packed(dst, op, base - cand, matched, lane);
                 next_emit = ip;
                 if (ip >= limit) {              // :388-389
                     done = true;
                     break;
                 }
                 win.ensure(ip - 1, lane);
-                table_put(table, win.hash_at(ip - 1), ip - 1);   // :391-392
+                table_put(table, win.hash_at(ip - 1), win.entry_at(ip - 1));   // :391-392
                 win.ensure(ip, lane);
                 const uint32_t here = win.bytes_at(ip);
-                cand = table_exchange(table, win.hash_at(ip), ip);   // :394-397
+                const uint32_t mine_e = win.entry_at(ip);
+                const uint32_t old = table_exchange(table, win.hash_at(ip), mine_e);   // :394-397
+                cand = old & 0xffffu;
+                if ((old ^ mine_e) >> 16) break;           // different tag: certain miss (:398)
                 cb.fetch(base16, start + cand);
                 if (here != cb.c0) break;                  // :396,:398
             }
@@ -521,11 +593,11 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
                                                                           uint32_t block_size, uint8_t* __restrict__ slots,
                                                                           uint32_t slot_stride,
                                                                           uint32_t* __restrict__ block_bytes,
-                                                                          uint32_t num_blocks, uint16_t* table_scratch,
+                                                                          uint32_t num_blocks, uint32_t* table_scratch,
                                                                           uint32_t* next_block)
 {
     const uint32_t lane = threadIdx.x;
-    uint16_t* __restrict__ table = table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
+    uint32_t* __restrict__ table = table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
     for (;;) {
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(next_block, 1u);

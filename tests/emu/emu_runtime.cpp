@@ -199,7 +199,7 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
     if (nb && variant == 3) {
         // persistent kernel: a few workgroups pull blocks from the shared counter
         const uint32_t grid = nb < 3 ? nb : 3;
-        std::vector<uint16_t> tables((size_t)grid * 16384, 0xBEEF);
+        std::vector<uint32_t> tables((size_t)grid * 16384, 0xBEEFBEEFu);
         uint32_t counter = 0;
         emu::launch(grid, 64, [&] {
             snappy_hip::compress_blocks_global_table_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb,
