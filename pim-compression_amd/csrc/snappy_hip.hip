@@ -204,7 +204,7 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
     hipStream_t st = (hipStream_t)stream;
     if (variant == kVariantGroup) {
         // ablation: 4 blocks per wavefront (16-lane groups); its tables are allocated lazily by the library
-        static thread_local uint16_t* group_tables = nullptr;
+        static thread_local uint32_t* group_tables = nullptr;
         static thread_local uint64_t group_table_slots = 0;
         const uint32_t waves = (uint32_t)env_int("SNAPPY_HIP_GROUP_WAVES", kGlobalTableWaves);
         const uint64_t want_groups = std::min<uint64_t>((uint64_t)waves * 4, (nb + 3) / 4 * 4);
@@ -212,7 +212,7 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
         if (group_table_slots < (uint64_t)g * 4) {
             if (group_tables) (void)hipFree(group_tables);
             group_tables = nullptr;
-            HIP_TRY(hipMalloc((void**)&group_tables, (size_t)g * 4 * snappy_hip::kMaxTableEntries * sizeof(uint16_t)));
+            HIP_TRY(hipMalloc((void**)&group_tables, (size_t)g * 4 * snappy_hip::kMaxTableEntries * sizeof(uint32_t)));
             group_table_slots = (uint64_t)g * 4;
         }
         hipLaunchKernelGGL(snappy_hip::compress_blocks_group_kernel, dim3(g), block, 0, st, d_in, input_len, block_size,

@@ -800,27 +800,42 @@ __device__ __forceinline__ uint32_t group_emit_copy(uint8_t* dst, uint32_t op, u
     return op + 3;
 }
 
+// broadcast a value from the group's leader lane to the whole 16-lane group (LDS crossbar, no memory)
+__device__ __forceinline__ uint32_t group_bcast(uint32_t v, uint32_t leader) { return (uint32_t)__shfl((int)v, (int)leader); }
+__device__ __forceinline__ uint64_t group_bcast64(uint64_t v, uint32_t leader)
+{
+    return (uint64_t)group_bcast((uint32_t)v, leader) | ((uint64_t)group_bcast((uint32_t)(v >> 32), leader) << 32);
+}
+
 __global__ __launch_bounds__(64) void compress_blocks_group_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
                                                                    uint32_t block_size, uint8_t* __restrict__ slots,
                                                                    uint32_t slot_stride, uint32_t* __restrict__ block_bytes,
-                                                                   uint32_t num_blocks, uint16_t* tables)
+                                                                   uint32_t num_blocks, uint32_t* tables)
 {
     enum : uint32_t { kInit = 0, kScan = 1, kCopy = 2, kDone = 3 };
     const uint32_t lane = threadIdx.x;
     const uint32_t gl = lane & (kGroupLanes - 1);
+    const uint32_t leader = lane & ~(kGroupLanes - 1);
+    const bool lead = gl == 0;
     const uint32_t groups_per_wave = kWave / kGroupLanes;
     const uint32_t slot = blockIdx.x * groups_per_wave + (lane / kGroupLanes);
     const uint32_t total_slots = gridDim.x * groups_per_wave;
-    uint16_t* table = tables + (size_t)slot * kMaxTableEntries;
+    uint32_t* table = tables + (size_t)slot * kMaxTableEntries;   // tagged entries: tag << 16 | position
 
     uint32_t mode = kInit;
     uint32_t b = slot;                         // next block of this group
     uint32_t n = 0, limit = 0, shift = 0, ip = 0, skip = 32, next_emit = 0, op = 4, cur_block = 0;
     const uint8_t* blk = in;
     uint8_t* dst = slots;
+    // cursor cache: the 16 bytes at block offset cbase, so most probes need no cursor load
+    uint32_t cbase = 0;
+    uint64_t clo = 0, chi = 0;
 
+    // Memory discipline: every (group-uniform) global load is issued by the group's leader lane only and
+    // broadcast with group_bcast -- 4 active lanes per wave-instruction instead of 64 redundant ones.
     while (__ballot(mode != kDone)) {
         // ---------------- block start (get_hash_table, snappy_compress.c:139-146, :288-301) ----------------
+        bool fresh = false;
         if (mode == kInit) {
             if (b >= num_blocks) {
                 mode = kDone;
@@ -832,37 +847,62 @@ __global__ __launch_bounds__(64) void compress_blocks_group_kernel(const uint8_t
                 n = (left < block_size) ? (uint32_t)left : block_size;
                 blk = in + start;
                 dst = slots + (uint64_t)cur_block * slot_stride;
-                const uint32_t ts = table_entries_for(n);
-                shift = (uint32_t)__builtin_clz(ts) + 1;
-                uint4* t = reinterpret_cast<uint4*>(table);
-                for (uint32_t i = gl; i < ts / 8; i += kGroupLanes) t[i] = make_uint4(0, 0, 0, 0);
                 op = 4;
                 next_emit = 0;
                 if (n < kInputMargin) {                          // whole block is one literal (:405-412)
                     op = group_emit_literal(dst, op, blk, n, gl);
-                    if (gl == 0) {
+                    if (lead) {
                         st32(dst, op - 4);
                         block_bytes[cur_block] = op;
                     }
                 } else {
+                    const uint32_t ts = table_entries_for(n);
+                    shift = (uint32_t)__builtin_clz(ts) + 1;
                     limit = n - kInputMargin;
                     ip = 1;
                     skip = 32;
+                    cbase = 0;
                     mode = kScan;
+                    fresh = true;
                 }
             }
         }
         const bool probing = (mode == kScan) || (mode == kCopy);
 
+        // ---------------- phase A0: (re)load the cursor cache when bytes ip-1 .. ip+6 are not inside it ----------------
+        const bool reload = probing && (fresh || ip - 1 < cbase || ip + 7 > cbase + 16);
+        if (__ballot(reload)) {
+            if (reload) {
+                if (!fresh) cbase = (ip - 1 + 16 <= n) ? ip - 1 : n - 16;
+                if (lead) {
+                    clo = ld64(blk + cbase);
+                    chi = (cbase + 16 <= n) ? ld64(blk + cbase + 8) : 0;   // only a 15-byte block lacks the 16th byte
+                }
+            }
+            clo = group_bcast64(clo, leader);
+            chi = group_bcast64(chi, leader);
+        }
+        if (fresh) {
+            // an empty slot means "candidate = position 0" (:346 on a zeroed table): store position 0's entry
+            const uint32_t e_zero = (((uint32_t)clo * kHashMul) << (32 - shift)) & 0xffff0000u;
+            const uint32_t ts = table_entries_for(n);
+            uint4* t = reinterpret_cast<uint4*>(table);
+            for (uint32_t i = gl; i < ts / 4; i += kGroupLanes) t[i] = make_uint4(e_zero, e_zero, e_zero, e_zero);
+        }
+
         // ---------------- phase A: cursor bytes; post-copy insert of ip-1 (:391-392) ----------------
-        uint32_t cur = 0, h = 0, next_ip = 0;
+        uint32_t cur = 0, h = 0, mine = 0, next_ip = 0;
         bool exhausted = false;
         if (probing) {
-            const uint64_t w = ld64(blk + ip - 1);               // bytes ip-1 .. ip+6
+            const uint32_t sh = 8 * (ip - 1 - cbase);            // 0..64 bits
+            const uint64_t w = (sh == 0) ? clo : ((sh < 64) ? ((clo >> sh) | (chi << (64 - sh))) : chi);
             cur = (uint32_t)(w >> 8);
-            h = (cur * kHashMul) >> shift;
+            const uint32_t prod = cur * kHashMul;
+            h = prod >> shift;
+            mine = ((prod << (32 - shift)) & 0xffff0000u) | ip;
             if (mode == kCopy) {
-                if (gl == 0) table[((uint32_t)w * kHashMul) >> shift] = (uint16_t)(ip - 1);
+                const uint32_t pprod = (uint32_t)w * kHashMul;
+                if (lead) table[pprod >> shift] = ((pprod << (32 - shift)) & 0xffff0000u) | (ip - 1);
             } else {
                 next_ip = ip + (skip >> 5);                      // :339-343
                 ++skip;
@@ -872,28 +912,45 @@ __global__ __launch_bounds__(64) void compress_blocks_group_kernel(const uint8_t
         __builtin_amdgcn_wave_barrier();
         // ---------------- phase B: candidate lookup (:346, :395) ----------------
         const bool lookup = probing && !exhausted;
-        uint32_t cand = 0;
-        if (lookup) cand = table[h];
-        __builtin_amdgcn_wave_barrier();
-        // ---------------- phase C: table update, hit test, emission, state update ----------------
-        if (lookup) {
-            if (gl == 0) table[h] = (uint16_t)ip;                // :347, :397
-            const uint64_t c01 = ld64(blk + cand);               // candidate bytes cand .. cand+7 (cand + 16 <= n)
-            const uint32_t c2 = ld32(blk + cand + 8);
-            if (cur != (uint32_t)c01) {
-                // miss: keep scanning (:348) or fall back from the copy chain to scanning (:398-401)
-                if (mode == kCopy) {
-                    mode = kScan;
-                    skip = 32;
-                    ip += 1;
-                } else {
-                    ip = next_ip;
-                }
+        uint32_t old = 0;
+        if (lookup && lead) old = table[h];
+        old = group_bcast(old, leader);
+        // ---------------- phase C: table update, hit test ----------------
+        if (lookup && lead) table[h] = mine;                     // :347, :397
+        const uint32_t cand = old & 0xffffu;
+        const bool tagmatch = lookup && (((old ^ mine) >> 16) == 0);
+        bool hit = false;
+        uint64_t c01 = 0;
+        uint32_t c2 = 0;
+        if (__ballot(tagmatch)) {                                // same tag: fetch candidate bytes (cand + 16 <= n)
+            if (tagmatch && lead) {
+                c01 = ld64(blk + cand);
+                c2 = ld32(blk + cand + 8);
+            }
+            c01 = group_bcast64(c01, leader);
+            c2 = group_bcast(c2, leader);
+            hit = tagmatch && (cur == (uint32_t)c01);
+        }
+        if (lookup && !hit) {
+            // miss: keep scanning (:348) or fall back from the copy chain to scanning (:398-401)
+            if (mode == kCopy) {
+                mode = kScan;
+                skip = 32;
+                ip += 1;
             } else {
+                ip = next_ip;
+            }
+        }
+        // ---------------- phase D: hit path -- literal, match length, copy (:355-389) ----------------
+        if (__ballot(hit)) {
+            uint64_t ahead = 0;
+            if (hit && lead) ahead = ld64(blk + ip + 4);
+            ahead = group_bcast64(ahead, leader);
+            if (hit) {
                 if (mode == kScan) op = group_emit_literal(dst, op, blk + next_emit, ip - next_emit, gl);   // :355
                 // find_match_length (:176-193): 8 bytes at once, then 8-byte / 1-byte steps
                 const uint64_t theirs = (c01 >> 32) | ((uint64_t)c2 << 32);
-                const uint64_t diff = ld64(blk + ip + 4) ^ theirs;
+                const uint64_t diff = ahead ^ theirs;
                 uint32_t matched;
                 if (diff) {
                     matched = 4 + ((uint32_t)__builtin_ctzll(diff) >> 3);
@@ -919,7 +976,7 @@ __global__ __launch_bounds__(64) void compress_blocks_group_kernel(const uint8_t
         }
         if (probing && exhausted) {                              // emit_remainder (:405-412)
             if (next_emit < n) op = group_emit_literal(dst, op, blk + next_emit, n - next_emit, gl);
-            if (gl == 0) {
+            if (lead) {
                 st32(dst, op - 4);
                 block_bytes[cur_block] = op;
             }

@@ -48,6 +48,7 @@ void syncthreads(int site);
 #define __builtin_amdgcn_readlane(v, l) ((int)emu::collective(emu::OP_READLANE, (uint64_t)(uint32_t)(v), (uint32_t)(l), __LINE__))
 #define __builtin_amdgcn_wave_barrier() ((void)emu::collective(emu::OP_BARRIER, 0, 0, __LINE__))
 #define __ballot(p) ((unsigned long long)emu::collective(emu::OP_BALLOT, (uint64_t)((p) ? 1 : 0), 0, __LINE__))
+#define __shfl(v, l) ((int)emu::collective(emu::OP_READLANE, (uint64_t)(uint32_t)(v), (uint32_t)(l), __LINE__))
 #define __shfl_up(v, d) ((int)emu::collective(emu::OP_SHFL_UP, (uint64_t)(uint32_t)(v), (uint32_t)(d), __LINE__))
 #define __syncthreads() emu::syncthreads(__LINE__)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
