@@ -91,3 +91,64 @@ def test_oracle_rejects_bad_offset():
     stream = bytes([5, 0x80, 0x80, 0x02]) + len(body).to_bytes(4, "little") + body
     st, _ = oracle.decompress(stream)
     assert st == 1
+
+
+def _decode_raw_snappy(buf):
+    """Minimal decoder of the ORIGINAL raw Snappy block format: varint(uncompressed length) + elements."""
+    n, shift, i = 0, 0, 0
+    while True:
+        c = buf[i]
+        i += 1
+        n |= (c & 0x7f) << shift
+        if c < 0x80:
+            break
+        shift += 7
+    out = bytearray()
+    while i < len(buf):
+        tag = buf[i]
+        i += 1
+        t = tag & 3
+        if t == 0:
+            ln = (tag >> 2) + 1
+            if ln > 60:
+                nb = ln - 60
+                ln = int.from_bytes(buf[i:i + nb], "little") + 1
+                i += nb
+            out += buf[i:i + ln]
+            i += ln
+            continue
+        if t == 1:
+            ln, off = ((tag >> 2) & 7) + 4, ((tag >> 5) << 8) | buf[i]
+            i += 1
+        elif t == 2:
+            ln, off = (tag >> 2) + 1, int.from_bytes(buf[i:i + 2], "little")
+            i += 2
+        else:
+            ln, off = (tag >> 2) + 1, int.from_bytes(buf[i:i + 4], "little")
+            i += 4
+        for _ in range(ln):
+            out.append(out[-off])
+    assert len(out) == n
+    return bytes(out)
+
+
+def test_blocks_are_raw_snappy_compatible():
+    """Interop (reference snappy/README.md:9-18): a block body prefixed with varint(block length) is a valid stream of
+    the original Snappy format, so standard decoders can read individual blocks."""
+    data = golden_bytes("terror2.txt")
+    stream = oracle.compress(data, 32768)
+    total, bs, _ = oracle.read_header(stream)
+    offs = oracle.index_blocks(stream)
+    out = bytearray()
+    for k, at in enumerate(offs):
+        at = int(at)
+        csz = int.from_bytes(stream[at:at + 4], "little")
+        blen = min(bs, total - k * bs)
+        varint = bytearray()
+        v = blen
+        while v >= 0x80:
+            varint.append((v & 0x7f) | 0x80)
+            v >>= 7
+        varint.append(v)
+        out += _decode_raw_snappy(bytes(varint) + stream[at + 4:at + 4 + csz])
+    assert bytes(out) == data
