@@ -5,7 +5,7 @@ One "step" = one pass of the hot path over one batch: every container of this ra
 (K1 per-block compress + scan/gather into the framed stream), then every stream is indexed (size-chain
 walk) and decompressed (K2).  Inputs are resident in HBM when the timed region starts.  One process per
 GPU; blocks/containers are independent, so ranks share nothing on the data path (no collective): each
-rank processes its own 8 x 1 GiB batch ("weak" scaling) and rank 0 reports the whole-job aggregate.
+rank processes its own 8 GiB batch (4 containers x 2 GiB: the format's length field is a uint32) ("weak" scaling) and rank 0 reports the whole-job aggregate.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -212,8 +212,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--containers", type=int, default=8, help="containers per GPU")
-    ap.add_argument("--container-mib", type=int, default=1024, help="container size in MiB (format limit: < 4096)")
+    ap.add_argument("--containers", type=int, default=4, help="containers per GPU")
+    ap.add_argument("--container-mib", type=int, default=2048, help="container size in MiB (format limit: < 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -215,8 +215,11 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
             HIP_TRY(hipMalloc((void**)&group_tables, (size_t)g * 4 * snappy_hip::kMaxTableEntries * sizeof(uint32_t)));
             group_table_slots = (uint64_t)g * 4;
         }
+        static thread_local uint32_t* group_counter = nullptr;
+        if (!group_counter) HIP_TRY(hipMalloc((void**)&group_counter, 256));
+        HIP_TRY(hipMemsetAsync(group_counter, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(snappy_hip::compress_blocks_group_kernel, dim3(g), block, 0, st, d_in, input_len, block_size,
-                           d_slots, slot_stride, d_block_bytes, (uint32_t)nb, group_tables);
+                           d_slots, slot_stride, d_block_bytes, (uint32_t)nb, group_tables, group_counter);
     } else if (variant == kVariantLanePerBlock) {
         static thread_local uint16_t* lane_tables = nullptr;
         static thread_local uint64_t lane_tables_blocks = 0;

@@ -70,3 +70,25 @@ def edge_cases(text):
 
 
 BLOCK_SIZES = (64, 255, 256, 257, 1000, 4096, 16384, 32768, 65535)
+
+
+def lz_structured(n, seed):
+    """Random LZ-like data: literals, back-references at random distances/lengths, runs -- exercises every element
+    type, offset class (1-byte / 2-byte), overlapping copies and the skip heuristic with randomised geometry."""
+    r = rng(seed)
+    out = bytearray(r.integers(0, 256, size=8, dtype=np.uint8).tobytes())
+    alphabet = int(r.choice([2, 4, 16, 64, 256]))
+    while len(out) < n:
+        k = r.random()
+        if k < 0.35:
+            out += r.integers(0, alphabet, size=int(r.integers(1, 40)), dtype=np.uint8).tobytes()
+        elif k < 0.85:
+            dist = int(r.choice([1, 2, 3, 4, 7, 8, 60, 64, 2047, 2048, 2049, 5000, 40000, 70000]))
+            dist = min(dist, len(out))
+            ln = int(r.choice([4, 5, 11, 12, 13, 59, 60, 64, 65, 67, 68, 69, 130, 1000]))
+            start = len(out) - dist
+            for i in range(ln):
+                out.append(out[start + i])
+        else:
+            out += bytes([int(r.integers(0, 256))]) * int(r.integers(1, 300))
+    return bytes(out[:n])

@@ -208,9 +208,10 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
     } else if (nb && variant == 5) {
         const uint32_t grid = nb < 8 ? 1 : 2;
         std::vector<uint32_t> tables((size_t)grid * 4 * 16384, 0xBEEFBEEFu);
+        uint32_t group_counter = 0;
         emu::launch(grid, 64, [&] {
             snappy_hip::compress_blocks_group_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb,
-                                                     tables.data());
+                                                     tables.data(), &group_counter);
         });
     } else if (nb)
         emu::launch(nb, 64, [&] {

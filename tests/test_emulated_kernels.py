@@ -58,6 +58,17 @@ def test_emulated_other_variants(cv, dv):
             assert st == 0 and out == data, (dv, bs)
 
 
+def test_emulated_seeded_fuzz():
+    for seed in range(10):
+        data = datagen.lz_structured(6000 + 900 * seed, seed)
+        for bs in (32768, 2048):
+            ref = oracle.compress(data, bs)
+            assert emu.compress(data, bs) == ref, (seed, bs)
+            total, got_bs, hdr = oracle.read_header(ref)
+            st, out = emu.decompress(ref, total, got_bs, hdr)
+            assert st == 0 and out == data, (seed, bs)
+
+
 def test_emulated_decoder_is_strict():
     # copy reaching before the block start
     body = bytes([0x00, 0x41, (3 << 2) | 2, 9, 0])

@@ -166,6 +166,20 @@ def test_batched_index_matches_scan_offsets(shb):
         assert int(ws.block_bytes[:nb].sum().item()) + int(ws.offsets[0].item()) == slen
 
 
+def test_seeded_fuzz_vs_oracle(shb):
+    r = np.random.default_rng(2026)
+    for seed in range(48):
+        n = int(r.integers(1, 260_000))
+        bs = int(r.choice([64, 100, 4096, 32768, 32769, 65535]))
+        if bs < 1000:
+            n = min(n, 30_000)
+        data = datagen.lz_structured(n, seed)
+        ref = oracle.compress(data, bs)
+        assert gpu_compress(shb, data, bs) == ref, (seed, n, bs)
+        st, out = gpu_decompress(shb, ref)
+        assert st == 0 and out == data, (seed, n, bs)
+
+
 # ---- every kernel variant produces the same bytes ------------------------------------------------------
 
 @pytest.mark.parametrize("env", [{"SNAPPY_HIP_COMPRESS_VARIANT": "1"}, {"SNAPPY_HIP_COMPRESS_VARIANT": "4"},
