@@ -96,6 +96,7 @@ int for_each_device(int count, const std::function<int(int)>& fn)
 
 constexpr int kVariantLdsTable = 1, kVariantGlobalTable = 3, kVariantLanePerBlock = 4, kVariantGroup = 5;
 constexpr int kDefaultDecompressVariant = 1;
+constexpr int kDefaultLdsWaves = 1024;   // 4 LDS-table wavefronts per CU beside 28 global-table ones (measured best)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 
 int env_int(const char* name, int fallback)
@@ -234,7 +235,7 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
                            input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, lane_tables, rep);
     } else if (variant == kVariantLdsTable) {
         hipLaunchKernelGGL(snappy_hip::compress_blocks_lds_table_kernel, grid, block, lds, st, d_in, input_len, block_size,
-                           d_slots, slot_stride, d_block_bytes, (uint32_t)nb);
+                           d_slots, slot_stride, d_block_bytes, (uint32_t)nb, (uint32_t*)nullptr);
     } else {
         // persistent grid, blocks handed out by an atomic counter kept in the first bytes of the scratch
         uint32_t waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", kGlobalTableWaves);
@@ -242,9 +243,32 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
         uint32_t* counter = static_cast<uint32_t*>(d_scratch);
         uint32_t* tables = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_scratch) + 256);
         HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
-        const uint32_t g = (uint32_t)std::min<uint64_t>(nb, waves);
-        hipLaunchKernelGGL(snappy_hip::compress_blocks_global_table_kernel, dim3(g), block, 0, st, d_in, input_len, block_size,
-                           d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);
+        // Hybrid launch: SNAPPY_HIP_LDS_WAVES workgroups of the LDS-table kernel run concurrently on a helper stream
+        // (5 fit per CU by LDS); both kernels draw blocks from the same counter, so the split balances itself.
+        uint32_t lds_waves = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", kDefaultLdsWaves);
+        if (nb < 4096) lds_waves = 0;                                  // small inputs: one kernel is enough
+        if (lds_waves > waves / 2) lds_waves = waves / 2;
+        const uint32_t g = (uint32_t)std::min<uint64_t>(nb, waves - lds_waves);
+        if (lds_waves) {
+            static thread_local hipStream_t helper = nullptr;
+            static thread_local hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+            if (!helper) {
+                HIP_TRY(hipStreamCreateWithFlags(&helper, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&ev_begin, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&ev_end, hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventRecord(ev_begin, st));                     // after the counter memset and all prior work
+            HIP_TRY(hipStreamWaitEvent(helper, ev_begin, 0));
+            hipLaunchKernelGGL(snappy_hip::compress_blocks_lds_table_kernel, dim3(lds_waves), block, 0, helper, d_in, input_len,
+                               block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, counter);
+            HIP_TRY(hipEventRecord(ev_end, helper));
+            hipLaunchKernelGGL(snappy_hip::compress_blocks_global_table_kernel, dim3(g), block, 0, st, d_in, input_len,
+                               block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);
+            HIP_TRY(hipStreamWaitEvent(st, ev_end, 0));                // the caller's stream resumes when both are done
+        } else {
+            hipLaunchKernelGGL(snappy_hip::compress_blocks_global_table_kernel, dim3(g), block, 0, st, d_in, input_len,
+                               block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);
+        }
     }
     HIP_TRY(hipGetLastError());
     return SNAPPY_HIP_OK;

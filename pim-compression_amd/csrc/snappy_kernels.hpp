@@ -171,150 +171,9 @@ __device__ __forceinline__ uint32_t match_extend(const uint8_t* __restrict__ blk
 }
 
 // ---------------------------------------------------------------------------
-// Input access of the LDS-table form of K1 (the fallback used when the caller passes no scratch).
-// ---------------------------------------------------------------------------
-
-// Wave-uniform reads through the scalar cache (s_load_dwordx2/x4 on aligned dwords + 64-bit shift),
-// which returns into SGPRs directly.  `base16` is the 16-byte aligned container base.
-struct InputGlobalScalar {
-    const uint8_t* __restrict__ blk;
-    const uint8_t* __restrict__ base16;
-    uint64_t start;
-    __device__ __forceinline__ void stage(const uint8_t* __restrict__ b, uint32_t, uint32_t, uint8_t*) { blk = b; }
-    __device__ __forceinline__ uint32_t u32(uint32_t p) const
-    {
-        const uint64_t a = start + p;
-        const uint32_t* w = static_cast<const uint32_t*>(__builtin_assume_aligned(base16 + (a & ~3ull), 4));
-        const uint64_t two = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-        return (uint32_t)(two >> (8 * (uint32_t)(a & 3)));
-    }
-    __device__ __forceinline__ uint64_t u64(uint32_t p) const
-    {
-        const uint64_t a = start + p;
-        const uint32_t* w = static_cast<const uint32_t*>(__builtin_assume_aligned(base16 + (a & ~3ull), 4));
-        const uint32_t sh = 8 * (uint32_t)(a & 3);
-        const uint64_t lo = ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) >> sh;
-        const uint64_t hi = ((uint64_t)w[1] | ((uint64_t)w[2] << 32)) >> sh;
-        return (uint64_t)(uint32_t)lo | ((uint64_t)(uint32_t)hi << 32);
-    }
-    __device__ __forceinline__ const uint8_t* bytes() const { return blk; }
-};
-
-// ---------------------------------------------------------------------------
-// K1, LDS-table form: one wavefront per block (grid-stride), u16 hash table in LDS (4-5 blocks/CU).
-// ---------------------------------------------------------------------------
-template <class Input>
-__device__ __forceinline__ void compress_one_block(Input& in, const uint8_t* __restrict__ blk_global, uint32_t n,
-                                                   uint8_t* __restrict__ dst, uint16_t* table, uint8_t* stage_buf,
-                                                   uint32_t lane, uint32_t* __restrict__ block_bytes_out)
-{
-    // get_hash_table, snappy_compress.c:139-146 (+ shift, :288)
-    const uint32_t ts = table_entries_for(n);
-    const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;   // 32 - log2(ts)
-    {
-        uint4* t = reinterpret_cast<uint4*>(table);
-        for (uint32_t i = lane; i < ts / 8; i += kWave) t[i] = make_uint4(0, 0, 0, 0);
-    }
-    in.stage(blk_global, n, lane, stage_buf);
-    __syncthreads();
-    const uint8_t* blk = in.bytes();   // per-lane (vector) reads: match extension
-
-    uint32_t op = 4;          // :291 room for the u32 size prefix
-    uint32_t next_emit = 0;   // :298
-
-    if (n >= kInputMargin) {  // :301
-        const uint32_t limit = n - kInputMargin;
-        uint32_t ip = 1;      // :305
-        uint32_t cur = in.u32(ip);        // bytes at ip
-        for (;;) {
-            // ---- step 1: scan for a 4-byte match (:333-348) ----
-            uint32_t skip = 32;
-            uint32_t cand;
-            bool out_of_input = false;
-            for (;;) {
-                const uint32_t h = (cur * kHashMul) >> shift;
-                const uint32_t next_ip = ip + (skip++ >> 5);
-                if (next_ip > limit) {          // :342-343, before touching the table
-                    out_of_input = true;
-                    break;
-                }
-                const uint32_t nxt = in.u32(next_ip);
-                cand = uni((uint32_t)table[h]);
-                if (lane == 0) table[h] = (uint16_t)ip;
-                __builtin_amdgcn_wave_barrier();
-                if (cur == in.u32(cand)) break;
-                ip = next_ip;
-                cur = nxt;
-            }
-            if (out_of_input) break;
-
-            // ---- step 2: literal run [next_emit, ip) (:355); payload copied from global memory ----
-            op = emit_literal(dst, op, blk_global + next_emit, ip - next_emit, lane);
-
-            // ---- step 3: copy chain (:370-398) ----
-            bool again;
-            bool done = false;
-            uint32_t tail = 0;     // le32(ip+1) after the chain, for the next scan
-            do {
-                const uint32_t base = ip;
-                const uint32_t matched = 4 + match_extend(blk, cand + 4, ip + 4, n, lane);
-                ip += matched;
-                op = emit_copy(dst, op, base - cand, matched, lane);
-                next_emit = ip;
-                if (ip >= limit) {              // :388-389
-                    done = true;
-                    break;
-                }
-                const uint64_t w = in.u64(ip - 1);               // bytes ip-1 .. ip+6
-                const uint32_t prev_bytes = (uint32_t)w;
-                const uint32_t here = (uint32_t)(w >> 8);
-                tail = (uint32_t)(w >> 16);
-                const uint32_t hp = (prev_bytes * kHashMul) >> shift;
-                const uint32_t hc = (here * kHashMul) >> shift;
-                if (lane == 0) table[hp] = (uint16_t)(ip - 1);   // :391-392
-                __builtin_amdgcn_wave_barrier();
-                cand = uni((uint32_t)table[hc]);                 // :394-395
-                if (lane == 0) table[hc] = (uint16_t)ip;         // :397
-                __builtin_amdgcn_wave_barrier();
-                again = (here == in.u32(cand));                  // :396,:398
-            } while (again);
-            if (done) break;
-
-            ++ip;                                                // :400-401
-            cur = tail;
-        }
-    }
-
-    // emit_remainder (:405-410) and the size prefix (:412)
-    if (next_emit < n) op = emit_literal(dst, op, blk_global + next_emit, n - next_emit, lane);
-    if (lane == 0) {
-        st32(dst, op - 4);
-        *block_bytes_out = op;
-    }
-    __syncthreads();   // table (and the staged block) are rewritten by the next iteration
-}
-
-__global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
-                                                                       uint32_t block_size, uint8_t* __restrict__ slots,
-                                                                       uint32_t slot_stride,
-                                                                       uint32_t* __restrict__ block_bytes, uint32_t num_blocks)
-{
-    __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTableEntries];
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t b = blockIdx.x; b < num_blocks; b += gridDim.x) {
-        const uint64_t start = (uint64_t)b * block_size;
-        const uint64_t left = in_len - start;
-        const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
-        const uint8_t* __restrict__ blk = in + start;
-        InputGlobalScalar src{blk, in, start};
-        compress_one_block(src, blk, n, slots + (uint64_t)b * slot_stride, table, nullptr, lane, block_bytes + b);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K1, windowed form (default).  Same parse as compress_one_block, restructured around what the
-// PMC profile showed to be the limits of the wave-uniform design: scalar-ALU issue (one scalar unit
-// per CU) and serialized memory round trips per probe.
+// K1, windowed form: one Snappy block per wavefront, the greedy parse of snappy_compress.c:284-413 as
+// wave-uniform control flow, structured around what the PMC profiles showed to limit it: instruction
+// issue on the scalar pipeline and serialized memory round trips per probe.
 //
 //  * Cursor side: a sliding register window.  Lane l holds x = le32(block + base + l) and its hash for
 //    the 64 positions of the current 64-byte granule, plus a prefetch of the next granule.  The bytes
@@ -323,9 +182,11 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uin
 //  * Candidate side: one 16-byte scalar load returns the 4 bytes for the hit test AND the next 8 bytes
 //    for the match extension, so a match of up to 12 bytes costs no further round trip; longer matches
 //    continue in the 64-lane extender.
-//  * Hash tables: one u16[16384] per resident wavefront in a global scratch (hot in L2 / Infinity
-//    Cache) so occupancy is bounded by registers (32 waves/CU), not LDS.  Persistent grid; blocks are
-//    handed out by an atomic counter (*next_block zeroed per launch).
+//  * Hash tables: templated.  TaggedGlobalTable = one u32[16384] per resident wavefront in a global scratch,
+//    so occupancy is bounded by registers (32 waves/CU), not LDS; LdsTable = the reference's u16[16384] in LDS
+//    (5 workgroups/CU).  The default launch runs BOTH kernels concurrently on one container: the LDS-table
+//    waves (lower table latency, no table traffic) take 4 of the 32 wave slots per CU, the global-table waves
+//    the rest; every wavefront draws its next block from one atomic counter (*next_block zeroed per launch).
 // Bit-exactness: identical decisions to snappy_compress.c:284-413; only where bytes are read from differs.
 // ---------------------------------------------------------------------------
 struct CursorWindow {
@@ -424,22 +285,55 @@ struct CandidateBytes {
 // The index is pinned into a VGPR so the access uses SGPR-base + VGPR-offset addressing, and every lane stores
 // the same value to the same address (one write on the wire, no exec-mask save/restore).  uni() sits between the
 // load and the store, so every lane has read before any lane writes.
-__device__ __forceinline__ uint32_t table_exchange(uint32_t* __restrict__ table, uint32_t h, uint32_t entry)
-{
-    uint32_t hv = h;
-    SNAPPY_PIN(hv);
-    const uint32_t old = uni(table[hv]);
-    table[hv] = entry;
-    __builtin_amdgcn_wave_barrier();
-    return old;
-}
-__device__ __forceinline__ void table_put(uint32_t* __restrict__ table, uint32_t h, uint32_t entry)
-{
-    uint32_t hv = h;
-    SNAPPY_PIN(hv);
-    table[hv] = entry;
-    __builtin_amdgcn_wave_barrier();
-}
+struct TaggedGlobalTable {      // u32 entries in the global scratch: tag << 16 | position
+    uint32_t* __restrict__ t;
+    __device__ __forceinline__ void init(uint32_t entries, uint32_t entry_zero, uint32_t lane) const
+    {
+        uint4* q = reinterpret_cast<uint4*>(t);
+        for (uint32_t i = lane; i < entries / 4; i += kWave) q[i] = make_uint4(entry_zero, entry_zero, entry_zero, entry_zero);
+    }
+    // returns the previous entry and stores `entry`
+    __device__ __forceinline__ uint32_t exchange(uint32_t h, uint32_t entry, uint32_t) const
+    {
+        uint32_t hv = h;
+        SNAPPY_PIN(hv);
+        const uint32_t old = uni(t[hv]);
+        t[hv] = entry;
+        __builtin_amdgcn_wave_barrier();
+        return old;
+    }
+    __device__ __forceinline__ void put(uint32_t h, uint32_t entry, uint32_t) const
+    {
+        uint32_t hv = h;
+        SNAPPY_PIN(hv);
+        t[hv] = entry;
+        __builtin_amdgcn_wave_barrier();
+    }
+    // true when the candidate stored in `old` can be skipped without looking at its bytes
+    __device__ __forceinline__ static bool certain_miss(uint32_t old, uint32_t entry) { return ((old ^ entry) >> 16) != 0; }
+};
+
+struct LdsTable {               // the reference's own layout: u16 positions, in LDS (no room for tags: 32 KiB per block)
+    uint16_t* t;
+    __device__ __forceinline__ void init(uint32_t entries, uint32_t, uint32_t lane) const
+    {
+        uint4* q = reinterpret_cast<uint4*>(t);
+        for (uint32_t i = lane; i < entries / 8; i += kWave) q[i] = make_uint4(0, 0, 0, 0);
+    }
+    __device__ __forceinline__ uint32_t exchange(uint32_t h, uint32_t entry, uint32_t lane) const
+    {
+        const uint32_t old = uni((uint32_t)t[h]);
+        if (lane == 0) t[h] = (uint16_t)entry;       // one lane: 64 same-address LDS writes would serialise
+        __builtin_amdgcn_wave_barrier();
+        return old;
+    }
+    __device__ __forceinline__ void put(uint32_t h, uint32_t entry, uint32_t lane) const
+    {
+        if (lane == 0) t[h] = (uint16_t)entry;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ static bool certain_miss(uint32_t, uint32_t) { return false; }
+};
 
 // Emitters of the windowed form.  Element headers are packed into one dword and stored by a single lane
 // (the 1-2 bytes past the header are overwritten by whatever is emitted next; every slot has >= 32 bytes of
@@ -486,9 +380,10 @@ __device__ __forceinline__ uint32_t emit_literal_windowed(uint8_t* __restrict__ 
     return op + hdr + len;
 }
 
+template <class Table>
 __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __restrict__ base16, uint64_t start,
                                                             uint64_t in_len, uint32_t n, uint8_t* __restrict__ dst,
-                                                            uint32_t* __restrict__ table, uint32_t lane,
+                                                            const Table table, uint32_t lane,
                                                             uint32_t* __restrict__ block_bytes_out)
 {
     const uint8_t* __restrict__ blk = base16 + start;
@@ -498,8 +393,7 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
     if (n >= kInputMargin) {
         // "empty" = candidate position 0 (:346 on a zeroed table), carrying position 0's tag
         const uint32_t e_zero = ((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u;
-        uint4* t = reinterpret_cast<uint4*>(table);
-        for (uint32_t i = lane; i < ts / 4; i += kWave) t[i] = make_uint4(e_zero, e_zero, e_zero, e_zero);
+        table.init(ts, e_zero, lane);
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -528,9 +422,9 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
                 const uint32_t next_ip = ip + (skip++ >> 5);
                 if (next_ip > limit) break;     // :342-343, before touching the table
                 const uint32_t mine = win.entry_at(ip);
-                const uint32_t old = table_exchange(table, h, mine);
+                const uint32_t old = table.exchange(h, mine, lane);
                 cand = old & 0xffffu;
-                if (((old ^ mine) >> 16) == 0) {                 // same tag: only now are the bytes worth fetching
+                if (!Table::certain_miss(old, mine)) {           // same tag: only now are the bytes worth fetching
                     cb.fetch(base16, start + cand);
                     if (cur == cb.c0) {
                         hit = true;
@@ -565,13 +459,13 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
                     break;
                 }
                 win.ensure(ip - 1, lane);
-                table_put(table, win.hash_at(ip - 1), win.entry_at(ip - 1));   // :391-392
+                table.put(win.hash_at(ip - 1), win.entry_at(ip - 1), lane);   // :391-392
                 win.ensure(ip, lane);
                 const uint32_t here = win.bytes_at(ip);
                 const uint32_t mine_e = win.entry_at(ip);
-                const uint32_t old = table_exchange(table, win.hash_at(ip), mine_e);   // :394-397
+                const uint32_t old = table.exchange(win.hash_at(ip), mine_e, lane);   // :394-397
                 cand = old & 0xffffu;
-                if ((old ^ mine_e) >> 16) break;           // different tag: certain miss (:398)
+                if (Table::certain_miss(old, mine_e)) break;   // different tag: certain miss (:398)
                 cb.fetch(base16, start + cand);
                 if (here != cb.c0) break;                  // :396,:398
             }
@@ -589,6 +483,37 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
     __builtin_amdgcn_wave_barrier();
 }
 
+// next_block == nullptr: static grid-stride assignment; otherwise blocks are drawn from the shared atomic counter,
+// which lets this kernel run CONCURRENTLY with compress_blocks_global_table_kernel on the same container (the
+// LDS-table waves fill 5 wave slots per CU with low-latency tables, the global-table waves the other 27).
+__global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
+                                                                       uint32_t block_size, uint8_t* __restrict__ slots,
+                                                                       uint32_t slot_stride,
+                                                                       uint32_t* __restrict__ block_bytes, uint32_t num_blocks,
+                                                                       uint32_t* next_block)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTableEntries];
+    const uint32_t lane = threadIdx.x;
+    uint32_t b = blockIdx.x;
+    for (;;) {
+        if (next_block) {
+            uint32_t drawn = 0;
+            if (lane == 0) drawn = atomicAdd(next_block, 1u);
+            b = uni(drawn);
+        }
+        if (b >= num_blocks) break;
+        const uint64_t start = (uint64_t)b * block_size;
+        const uint64_t left = in_len - start;
+        const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
+        const uint8_t* __restrict__ blk = in + start;
+        (void)blk;
+        compress_one_block_windowed(in, start, in_len, n, slots + (uint64_t)b * slot_stride, LdsTable{table}, lane,
+                                    block_bytes + b);
+        __syncthreads();
+        b += gridDim.x;
+    }
+}
+
 __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
                                                                           uint32_t block_size, uint8_t* __restrict__ slots,
                                                                           uint32_t slot_stride,
@@ -597,7 +522,7 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
                                                                           uint32_t* next_block)
 {
     const uint32_t lane = threadIdx.x;
-    uint32_t* __restrict__ table = table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
+    const TaggedGlobalTable table{table_scratch + (size_t)blockIdx.x * kMaxTableEntries};
     for (;;) {
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(next_block, 1u);

@@ -219,7 +219,8 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
                 if (emu::bidx().x * 64 < nb)
                     snappy_hip::compress_blocks_lane_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, lane_tables.data(), 1);
             } else
-                snappy_hip::compress_blocks_lds_table_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb);
+                snappy_hip::compress_blocks_lds_table_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb,
+                                                             nullptr);
         });
     emu::launch(1, 1024, [&] {
         snappy_hip::scan_block_bytes_kernel(bytes.data(), nb, (uint32_t)n, block_size, stream, offsets.data(), &stream_len);
