@@ -11,6 +11,7 @@
 #include <string.h>
 #include <sys/time.h>
 
+#include <atomic>
 #include <functional>
 #include <string>
 #include <thread>
@@ -95,9 +96,24 @@ int for_each_device(int count, const std::function<int(int)>& fn)
 }
 
 constexpr int kVariantLdsTable = 1, kVariantGlobalTable = 3, kVariantLanePerBlock = 4, kVariantGroup = 5;
-constexpr int kDefaultDecompressVariant = 1;
+constexpr int kDefaultDecompressVariant = 1;   // the concurrent LDS+global form (2) measured no faster for K2
 constexpr int kDefaultLdsWaves = 1024;   // 4 LDS-table wavefronts per CU beside 28 global-table ones (measured best)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
+
+// Work counters for persistent kernels: a small ring in the code object's own global memory, so launches need no
+// allocation; each launch takes the next slot and zeroes it on its stream (up to 64 launches may be in flight).
+__device__ uint32_t g_work_counters[64 * 16];
+
+int next_work_counter(uint32_t** out, hipStream_t st)
+{
+    static std::atomic<uint32_t> turn{0};
+    uint32_t* base = nullptr;
+    HIP_TRY(hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_work_counters)));
+    uint32_t* c = base + (turn.fetch_add(1) & 63u) * 16;      // one counter per 64-byte line
+    HIP_TRY(hipMemsetAsync(c, 0, sizeof(uint32_t), st));
+    *out = c;
+    return 0;
+}
 
 int env_int(const char* name, int fallback)
 {
@@ -311,14 +327,42 @@ int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, c
     if (!d_stream || !d_block_offsets || !d_out || !d_status) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
     const uint64_t nb = snappy_hip_num_blocks(total_len, block_size);
     if (nb > 0x7fffffffull) return fail(SNAPPY_HIP_ERR_ARG, "too many blocks");
-    // SNAPPY_HIP_DECOMPRESS_VARIANT: 0 = output window in LDS, 1 = output window in global memory (default)
-    if (env_int("SNAPPY_HIP_DECOMPRESS_VARIANT", kDefaultDecompressVariant) == 0) {
-        const uint32_t lds = (block_size + 15u) & ~15u;
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3((uint32_t)nb), dim3(64), lds, (hipStream_t)stream,
-                           d_stream, stream_len, d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb);
+    // SNAPPY_HIP_DECOMPRESS_VARIANT: 0 = output window in LDS only, 1 (default) = output window in global memory only,
+    // 2 = both forms concurrently (no gain measured for K2, kept as an ablation): SNAPPY_HIP_K2_LDS_WAVES LDS-window wavefronts on a helper stream beside
+    // the global-window ones, all drawing blocks from one counter.
+    const int variant = env_int("SNAPPY_HIP_DECOMPRESS_VARIANT", kDefaultDecompressVariant);
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* counter = nullptr;
+    if (int rc = next_work_counter(&counter, st)) return rc;
+    const uint32_t lds_bytes = (block_size + 15u) & ~15u;
+    const uint32_t resident = kGlobalTableWaves;
+    uint32_t lds_waves = 0;
+    if (variant == 0) lds_waves = (uint32_t)std::min<uint64_t>(nb, resident);
+    else if (variant == 2 && nb >= 4096)
+        lds_waves = (uint32_t)env_int("SNAPPY_HIP_K2_LDS_WAVES", lds_bytes > 32768 ? 512 : 1024);
+    const uint32_t glob_waves = (variant == 0) ? 0 : (uint32_t)std::min<uint64_t>(nb, resident - std::min(lds_waves, resident / 2));
+    if (lds_waves && glob_waves) {
+        static thread_local hipStream_t helper = nullptr;
+        static thread_local hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+        if (!helper) {
+            HIP_TRY(hipStreamCreateWithFlags(&helper, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ev_begin, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ev_end, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(ev_begin, st));
+        HIP_TRY(hipStreamWaitEvent(helper, ev_begin, 0));
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, helper, d_stream,
+                           stream_len, d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb, counter);
+        HIP_TRY(hipEventRecord(ev_end, helper));
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<false>, dim3(glob_waves), dim3(64), 0, st, d_stream, stream_len,
+                           d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb, counter);
+        HIP_TRY(hipStreamWaitEvent(st, ev_end, 0));
+    } else if (lds_waves) {
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, st, d_stream,
+                           stream_len, d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb, counter);
     } else {
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<false>, dim3((uint32_t)nb), dim3(64), 0, (hipStream_t)stream,
-                           d_stream, stream_len, d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb);
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<false>, dim3(glob_waves), dim3(64), 0, st, d_stream, stream_len,
+                           d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb, counter);
     }
     HIP_TRY(hipGetLastError());
     return SNAPPY_HIP_OK;

@@ -250,11 +250,14 @@ int emu_decompress_variant(const uint8_t* stream, uint64_t stream_len, uint32_t 
     emu::launch(1, 64, [&] { snappy_hip::index_streams_kernel(&d, 1); });
     if (result[0] != 0 || result[1] != nb) return 1;
     std::vector<uint32_t> status(nb, 9);
-    emu::launch(nb, 64, [&] {
+    uint32_t k2_counter = 0;
+    emu::launch(nb < 3 ? nb : 3, 64, [&] {
         if (variant == 0)
-            snappy_hip::decompress_blocks_kernel<true>(stream, stream_len, boff.data(), total_len, block_size, out, status.data(), nb);
+            snappy_hip::decompress_blocks_kernel<true>(stream, stream_len, boff.data(), total_len, block_size, out, status.data(), nb,
+                                                       &k2_counter);
         else
-            snappy_hip::decompress_blocks_kernel<false>(stream, stream_len, boff.data(), total_len, block_size, out, status.data(), nb);
+            snappy_hip::decompress_blocks_kernel<false>(stream, stream_len, boff.data(), total_len, block_size, out, status.data(), nb,
+                                                        &k2_counter);
     });
     for (uint32_t i = 0; i < nb; ++i)
         if (status[i] != 0) return 1;
