@@ -262,7 +262,7 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
         // Hybrid launch: SNAPPY_HIP_LDS_WAVES workgroups of the LDS-table kernel run concurrently on a helper stream
         // (5 fit per CU by LDS); both kernels draw blocks from the same counter, so the split balances itself.
         uint32_t lds_waves = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", kDefaultLdsWaves);
-        if (nb < 4096) lds_waves = 0;                                  // small inputs: one kernel is enough
+        if (nb < (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096)) lds_waves = 0;                                  // small inputs: one kernel is enough
         if (lds_waves > waves / 2) lds_waves = waves / 2;
         const uint32_t g = (uint32_t)std::min<uint64_t>(nb, waves - lds_waves);
         if (lds_waves) {
@@ -338,7 +338,7 @@ int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, c
     const uint32_t resident = kGlobalTableWaves;
     uint32_t lds_waves = 0;
     if (variant == 0) lds_waves = (uint32_t)std::min<uint64_t>(nb, resident);
-    else if (variant == 2 && nb >= 4096)
+    else if (variant == 2 && nb >= (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096))
         lds_waves = (uint32_t)env_int("SNAPPY_HIP_K2_LDS_WAVES", lds_bytes > 32768 ? 512 : 1024);
     const uint32_t glob_waves = (variant == 0) ? 0 : (uint32_t)std::min<uint64_t>(nb, resident - std::min(lds_waves, resident / 2));
     if (lds_waves && glob_waves) {

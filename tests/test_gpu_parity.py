@@ -188,7 +188,10 @@ def test_seeded_fuzz_vs_oracle(shb):
                                  {"SNAPPY_HIP_COMPRESS_VARIANT": "5"},
                                  {"SNAPPY_HIP_COMPRESS_VARIANT": "5", "SNAPPY_HIP_GROUP_WAVES": "3"},
                                  {"SNAPPY_HIP_LDS_WAVES": "0"},
-                                 {"SNAPPY_HIP_DECOMPRESS_VARIANT": "0"}, {"SNAPPY_HIP_DECOMPRESS_VARIANT": "2"}])
+                                 {"SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11", "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"},
+                                 {"SNAPPY_HIP_DECOMPRESS_VARIANT": "0"},
+                                 {"SNAPPY_HIP_DECOMPRESS_VARIANT": "2", "SNAPPY_HIP_K2_LDS_WAVES": "3",
+                                  "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"}])
 def test_kernel_variants_bit_exact(shb, env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
