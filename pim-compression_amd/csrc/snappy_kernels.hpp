@@ -1044,9 +1044,11 @@ __global__ __launch_bounds__(64) void index_streams_kernel(const StreamDesc* __r
 //  * Every lane pre-decodes "the element that would start at my byte" (type, header size, output length,
 //    offset) -- 64 candidate starts per window in a handful of VALU instructions.  The real element chain
 //    is then followed with v_readlane only: no memory access to parse a tag.
-//  * Literal payloads are stored to the LDS output window straight from the window registers (lane l's
-//    byte 0 IS compressed byte g+l); back-references are LDS->LDS replications (`lane % offset` by
-//    reciprocal multiply); the finished block leaves LDS with coalesced 16 B/lane stores.
+//  * Literal payloads are stored to the output window straight from the window registers (lane l's
+//    byte 0 IS compressed byte g+l); back-references are window->window replications (`lane % offset` by
+//    reciprocal multiply), one gather/scatter per copy element.  (Packing several independent copies into one
+//    64-lane gather/scatter was measured slower in both window forms: its lane bookkeeping costs more issue
+//    slots than the round trips it saves once 24-32 wavefronts per CU hide them.)
 //
 // Semantics: snappy_decompress.c:232-285 on well-formed streams, strict otherwise (per-block status).
 // ---------------------------------------------------------------------------
@@ -1155,24 +1157,6 @@ __global__ __launch_bounds__(64) void decompress_blocks_kernel(const uint8_t* __
         uint64_t w0 = 0;
         WindowLoad next = {0, 64};  // prefetch of the following 64 bytes (W1), shift applied at use
         bool have_window = false;
-        // Pending back-reference batch: up to 64 output bytes of consecutive copy elements whose sources are
-        // already final.  Lane k of the batch copies win[bsrc] -> win[bdst]; one LDS round trip per flush.
-        uint32_t bsrc = 0, bdst = 0;     // per lane
-        uint32_t bfill = 0;              // lanes in use (wave-uniform)
-        uint32_t bfirst = 0;             // output position of the first byte of the batch
-
-#define SNAPPY_FLUSH_COPIES()                                   \
-    do {                                                        \
-        if (bfill) {                                            \
-            uint8_t v_ = 0;                                     \
-            if (lane < bfill) v_ = win[bsrc];                   \
-            __builtin_amdgcn_wave_barrier();                    \
-            if (lane < bfill) win[bdst] = v_;                   \
-            __builtin_amdgcn_wave_barrier();                    \
-            bfill = 0;                                          \
-        }                                                       \
-    } while (0)
-
         while (st == kBlockOk && cp < csz) {                             // one iteration per 64-byte window
             if (!have_window || cp >= g + 128) {
                 g = cp & ~63u;
@@ -1198,7 +1182,6 @@ __global__ __launch_bounds__(64) void decompress_blocks_kernel(const uint8_t* __
                     break;
                 }
                 if (type == 0) {                                         // literal, :244-256
-                    // Literal bytes land at >= op, pending copies only read < their own op <= op: no flush needed.
                     const uint32_t rel = s + hdr;                        // payload start relative to g
                     if (rel + len <= 128) {
                         // payload bytes are byte 0 of window lanes rel .. rel+len-1
@@ -1228,27 +1211,22 @@ __global__ __launch_bounds__(64) void decompress_blocks_kernel(const uint8_t* __
                 }
                 // :174-181 forward byte copy == periodic replication of the last `off` bytes.
                 // Source bytes are [op-off, op-off+min(len,off)); they must not be pending in the batch.
-                const uint32_t span = (len < off) ? len : off;
-                if (bfill + len > kWave || (bfill && op - off + span > bfirst)) SNAPPY_FLUSH_COPIES();
-                if (bfill == 0) bfirst = op;
-                {
-                    const uint32_t idx = lane - bfill;                   // wraps for lanes below bfill
-                    uint32_t src_idx = idx;
-                    if (off < len) {                                     // overlap: idx % off (idx < 64, off < 64)
-                        const uint32_t q = ((idx & 63) * kRecip16[off]) >> 16;
-                        src_idx = idx - q * off;
+                {   // :174-181 forward byte copy == periodic replication of the last `off` bytes
+                    uint32_t src_idx = lane;
+                    if (off < len) {                                     // overlap: lane % off (lane < 64, off < 64)
+                        const uint32_t q = (lane * kRecip16[off]) >> 16;
+                        src_idx = lane - q * off;
                     }
-                    const bool mine = idx < len;
-                    bsrc = mine ? (op - off + src_idx) : bsrc;
-                    bdst = mine ? (op + idx) : bdst;
+                    uint8_t v = 0;
+                    if (lane < len) v = win[op - off + src_idx];
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < len) win[op + lane] = v;
+                    __builtin_amdgcn_wave_barrier();
                 }
-                bfill += len;
                 cp += hdr;
                 op += len;
             }
         }
-        SNAPPY_FLUSH_COPIES();
-#undef SNAPPY_FLUSH_COPIES
         if (st == kBlockOk && (op != out_len || cp != csz)) st = kBlockInvalid;
 
         // write-out: LDS -> global, 16 B per lane when the destination allows it
