@@ -1217,10 +1217,9 @@ __global__ __launch_bounds__(64) void decompress_blocks_kernel(const uint8_t* __
                         const uint32_t q = (lane * kRecip16[off]) >> 16;
                         src_idx = lane - q * off;
                     }
-                    uint8_t v = 0;
-                    if (lane < len) v = win[op - off + src_idx];
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < len) win[op + lane] = v;
+                    // every source byte lies before `op` and every destination at or after it, so the lanes of
+                    // one element never depend on each other: one predicated load+store, one barrier afterwards
+                    if (lane < len) win[op + lane] = win[op - off + src_idx];
                     __builtin_amdgcn_wave_barrier();
                 }
                 cp += hdr;
