@@ -142,7 +142,8 @@ uint32_t snappy_hip_parse_header(const uint8_t *src, uint64_t avail, uint32_t *t
  * d_scratch: 256-byte aligned device workspace of snappy_hip_compress_scratch_bytes() bytes (one 64 KiB
  * tagged hash table per resident wavefront + a work counter; contents need not be initialised, the buffer must
  * not be shared by launches that run concurrently).  If NULL or too small the LDS-table kernel is used
- * instead (lower occupancy, same bytes).
+ * instead (lower occupancy, same bytes).  After the launch, the u32 at byte 16 of the scratch holds the number
+ * of blocks that were compressed by the LDS-table wavefronts of the concurrent launch (statistics only).
  */
 uint64_t snappy_hip_compress_scratch_bytes(void);
 int snappy_hip_compress_blocks(const uint8_t *d_in, uint64_t input_len, uint32_t block_size,

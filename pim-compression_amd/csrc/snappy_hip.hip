@@ -258,7 +258,7 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
         if (waves > kGlobalTableWaves) waves = kGlobalTableWaves;
         uint32_t* counter = static_cast<uint32_t*>(d_scratch);
         uint32_t* tables = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_scratch) + 256);
-        HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(counter, 0, 32, st));   // [0] next block, [4] blocks compressed by the LDS-table form
         // Hybrid launch: SNAPPY_HIP_LDS_WAVES workgroups of the LDS-table kernel run concurrently on a helper stream
         // (5 fit per CU by LDS); both kernels draw blocks from the same counter, so the split balances itself.
         uint32_t lds_waves = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", kDefaultLdsWaves);

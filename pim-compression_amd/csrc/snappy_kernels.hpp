@@ -509,6 +509,7 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uin
         (void)blk;
         compress_one_block_windowed(in, start, in_len, n, slots + (uint64_t)b * slot_stride, LdsTable{table}, lane,
                                     block_bytes + b);
+        if (next_block && lane == 0) atomicAdd(next_block + 4, 1u);   // statistics: blocks taken by the LDS-table form
         __syncthreads();
         b += gridDim.x;
     }

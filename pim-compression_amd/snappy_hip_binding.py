@@ -138,6 +138,7 @@ class CompressWorkspace:
 
     def __init__(self, max_len, block_size, device="cuda"):
         import torch
+        self._torch = torch
         self.block_size = block_size
         self.max_len = max_len
         self.stride = slot_stride(block_size)
@@ -149,6 +150,11 @@ class CompressWorkspace:
         self.scratch_bytes = int(lib().snappy_hip_compress_scratch_bytes())
         self.scratch = torch.empty(self.scratch_bytes + 256, dtype=torch.uint8, device=device)
         self.scratch_ptr = (self.scratch.data_ptr() + 255) & ~255
+
+    def lds_form_blocks(self):
+        """Blocks of the last compress_blocks() launch that were taken by the LDS-table wavefronts (statistics)."""
+        off = self.scratch_ptr - self.scratch.data_ptr()
+        return int(self.scratch[off + 16:off + 20].view(self._torch.int32).item())
 
     def stream_capacity(self, n):
         return int(lib().snappy_hip_stream_bound(n, self.block_size))

@@ -32,4 +32,4 @@ for _ in range(reps):
     slen = int(ws.stream_len.item())
     shb.decompress_blocks(d_stream, slen, ws.offsets[:nb].contiguous(), n, 32768, out, status)
 torch.cuda.synchronize()
-print("ok", torch.equal(out[:n], d_in[:n]), slen)
+print("ok", torch.equal(out[:n], d_in[:n]), slen, "lds_form_blocks", ws.lds_form_blocks(), "of", nb)
