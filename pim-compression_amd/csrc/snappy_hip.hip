@@ -121,17 +121,26 @@ int env_int(const char* name, int fallback)
     return (v && *v) ? atoi(v) : fallback;
 }
 
+// Number of shards the drop-in pair splits a file into: SNAPPY_HIP_NUM_GPUS (default: every visible device).
+// SNAPPY_HIP_OVERSUBSCRIBE=1 (test hook) allows more shards than devices; shard g then runs on device
+// g % device_count, so the sharding and host-side concat paths can be exercised on a one-GPU box.
+int g_physical_devices = 1;
+
 int requested_gpus()
 {
     int have = 0;
     if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return 0;
+    g_physical_devices = have;
     const char* env = getenv("SNAPPY_HIP_NUM_GPUS");
     if (env && *env) {
         const int want = atoi(env);
-        if (want >= 1 && want < have) have = want;
+        const bool over = env_int("SNAPPY_HIP_OVERSUBSCRIBE", 0) != 0;
+        if (want >= 1 && (want < have || (over && want <= 64))) have = want;
     }
     return have;
 }
+
+hipError_t set_shard_device(int shard) { return hipSetDevice(shard % g_physical_devices); }
 
 }  // namespace
 
@@ -450,7 +459,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     t0 = now_seconds();
     int rc = for_each_device(gpus, [&](int g) -> int {
         CompressShard& s = sh[g];
-        HIP_TRY(hipSetDevice(g));
+        HIP_TRY(set_shard_device(g));
         if (!s.num_blocks) return 0;
         HIP_TRY(hipMalloc((void**)&s.d_in, s.in_len + 16));
         HIP_TRY(hipMalloc((void**)&s.d_slots, s.num_blocks * (uint64_t)stride));
@@ -467,7 +476,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     // load (dpu_load, :541): force the code object onto each device
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
-        HIP_TRY(hipSetDevice(g));
+        HIP_TRY(set_shard_device(g));
         hipFuncAttributes fa;
         HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel)));
         HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::gather_slots_kernel)));
@@ -480,7 +489,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         CompressShard& s = sh[g];
-        HIP_TRY(hipSetDevice(g));
+        HIP_TRY(set_shard_device(g));
         if (s.num_blocks) HIP_TRY(hipMemcpy(s.d_in, input->buffer + s.in_off, s.in_len, hipMemcpyHostToDevice));
         return 0;
     });
@@ -491,7 +500,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         CompressShard& s = sh[g];
-        HIP_TRY(hipSetDevice(g));
+        HIP_TRY(set_shard_device(g));
         if (!s.num_blocks) return 0;
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0));
@@ -516,7 +525,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         CompressShard& s = sh[g];
-        HIP_TRY(hipSetDevice(g));
+        HIP_TRY(set_shard_device(g));
         if (!s.num_blocks) return 0;
         HIP_TRY(hipMemcpy(&s.stream_len, s.d_stream_len, sizeof(uint64_t), hipMemcpyDeviceToHost));
         uint8_t tmp[10];
@@ -541,7 +550,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     }
     rc = for_each_device(gpus, [&](int g) -> int {
         CompressShard& s = sh[g];
-        HIP_TRY(hipSetDevice(g));
+        HIP_TRY(set_shard_device(g));
         if (s.num_blocks)
             HIP_TRY(hipMemcpy(output->buffer + s.out_off, s.d_stream + s.local_hdr, s.stream_len - s.local_hdr, hipMemcpyDeviceToHost));
         return 0;
@@ -558,7 +567,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         CompressShard& s = sh[g];
-        HIP_TRY(hipSetDevice(g));
+        HIP_TRY(set_shard_device(g));
         (void)hipFree(s.d_in);
         (void)hipFree(s.d_slots);
         (void)hipFree(s.d_bytes);
@@ -642,7 +651,7 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
     t0 = now_seconds();
     int rc = for_each_device(gpus, [&](int g) -> int {
         DecompressShard& s = sh[g];
-        HIP_TRY(hipSetDevice(g));
+        HIP_TRY(set_shard_device(g));
         if (!s.num_blocks) return 0;
         HIP_TRY(hipMalloc((void**)&s.d_stream, s.in_len + 16));
         HIP_TRY(hipMalloc((void**)&s.d_boff, s.num_blocks * sizeof(uint64_t)));
@@ -655,7 +664,7 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
 
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
-        HIP_TRY(hipSetDevice(g));
+        HIP_TRY(set_shard_device(g));
         hipFuncAttributes fa;
         HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel<false>)));
         return 0;
@@ -666,7 +675,7 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         DecompressShard& s = sh[g];
-        HIP_TRY(hipSetDevice(g));
+        HIP_TRY(set_shard_device(g));
         if (!s.num_blocks) return 0;
         HIP_TRY(hipMemcpy(s.d_stream, buf + s.in_off, s.in_len, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s.d_boff, s.rel_off.data(), s.num_blocks * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -678,7 +687,7 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         DecompressShard& s = sh[g];
-        HIP_TRY(hipSetDevice(g));
+        HIP_TRY(set_shard_device(g));
         if (!s.num_blocks) return 0;
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0));
@@ -699,7 +708,7 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         DecompressShard& s = sh[g];
-        HIP_TRY(hipSetDevice(g));
+        HIP_TRY(set_shard_device(g));
         if (!s.num_blocks) return 0;
         std::vector<uint32_t> st(s.num_blocks);
         HIP_TRY(hipMemcpy(st.data(), s.d_status, s.num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -717,7 +726,7 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         DecompressShard& s = sh[g];
-        HIP_TRY(hipSetDevice(g));
+        HIP_TRY(set_shard_device(g));
         (void)hipFree(s.d_stream);
         (void)hipFree(s.d_boff);
         (void)hipFree(s.d_out);

@@ -79,6 +79,27 @@ def test_dropin_pair_host_buffers(shb, name):
     assert rt["run"] > 0
 
 
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_dropin_pair_sharding_and_concat(shb, shards, monkeypatch):
+    """Contiguous block ranges per device + host-side concat (reference snappy_compress.c:494-520, :697-704):
+    more shards than devices are mapped round-robin onto the available GPU(s), output must not change."""
+    monkeypatch.setenv("SNAPPY_HIP_NUM_GPUS", str(shards))
+    monkeypatch.setenv("SNAPPY_HIP_OVERSUBSCRIBE", "1")
+    for name in ("terror2", "plrabn12", "world192"):
+        txt, snp = golden_bytes(name + ".txt"), golden_bytes(name + ".snappy")
+        st, stream, _ = shb.compress_host(txt, 32768)
+        assert st == 0 and stream == snp, (name, shards)
+        st, plain, _ = shb.decompress_host(snp)
+        assert st == 0 and plain == txt, (name, shards)
+    data = datagen.text_random_interleave(golden_bytes("plrabn12.txt"), 1_000_003)
+    for bs in (4097, 65535):
+        ref = oracle.compress(data, bs, threads=8)
+        st, stream, _ = shb.compress_host(data, bs)
+        assert st == 0 and stream == ref, (bs, shards)
+        st, plain, _ = shb.decompress_host(ref)
+        assert st == 0 and plain == data, (bs, shards)
+
+
 def test_dropin_rejects_bad_block_size_and_streams(shb):
     st, _, _ = shb.compress_host(b"x" * 100, 0)
     assert st != 0
