@@ -115,6 +115,30 @@ int next_work_counter(uint32_t** out, hipStream_t st)
     return 0;
 }
 
+// Helper stream + fork/join events for launches that co-run two kernels, one set per (host thread, device):
+// created on first use on that device and reused.  The events are timing-disabled; the helper stream is
+// non-blocking, so the only ordering is the explicit fork (ev_begin) and join (ev_end) around the caller's stream.
+struct CoRunResources {
+    hipStream_t helper = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+};
+
+int corun_resources(CoRunResources** out)
+{
+    static thread_local CoRunResources per_device[64];
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(SNAPPY_HIP_ERR_ARG, "device index out of range");
+    CoRunResources& r = per_device[dev];
+    if (!r.helper) {
+        HIP_TRY(hipStreamCreateWithFlags(&r.helper, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&r.ev_begin, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&r.ev_end, hipEventDisableTiming));
+    }
+    *out = &r;
+    return 0;
+}
+
 int env_int(const char* name, int fallback)
 {
     const char* v = getenv(name);
@@ -275,13 +299,10 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
         if (lds_waves > waves / 2) lds_waves = waves / 2;
         const uint32_t g = (uint32_t)std::min<uint64_t>(nb, waves - lds_waves);
         if (lds_waves) {
-            static thread_local hipStream_t helper = nullptr;
-            static thread_local hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-            if (!helper) {
-                HIP_TRY(hipStreamCreateWithFlags(&helper, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&ev_begin, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&ev_end, hipEventDisableTiming));
-            }
+            CoRunResources* cr = nullptr;
+            if (int rc = corun_resources(&cr)) return rc;
+            hipStream_t helper = cr->helper;
+            hipEvent_t ev_begin = cr->ev_begin, ev_end = cr->ev_end;
             HIP_TRY(hipEventRecord(ev_begin, st));                     // after the counter memset and all prior work
             HIP_TRY(hipStreamWaitEvent(helper, ev_begin, 0));
             hipLaunchKernelGGL(snappy_hip::compress_blocks_lds_table_kernel, dim3(lds_waves), block, 0, helper, d_in, input_len,
@@ -351,13 +372,10 @@ int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, c
         lds_waves = (uint32_t)env_int("SNAPPY_HIP_K2_LDS_WAVES", lds_bytes > 32768 ? 512 : 1024);
     const uint32_t glob_waves = (variant == 0) ? 0 : (uint32_t)std::min<uint64_t>(nb, resident - std::min(lds_waves, resident / 2));
     if (lds_waves && glob_waves) {
-        static thread_local hipStream_t helper = nullptr;
-        static thread_local hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-        if (!helper) {
-            HIP_TRY(hipStreamCreateWithFlags(&helper, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ev_begin, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&ev_end, hipEventDisableTiming));
-        }
+        CoRunResources* cr = nullptr;
+        if (int rc = corun_resources(&cr)) return rc;
+        hipStream_t helper = cr->helper;
+        hipEvent_t ev_begin = cr->ev_begin, ev_end = cr->ev_end;
         HIP_TRY(hipEventRecord(ev_begin, st));
         HIP_TRY(hipStreamWaitEvent(helper, ev_begin, 0));
         hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, helper, d_stream,

@@ -152,3 +152,19 @@ def test_blocks_are_raw_snappy_compatible():
         varint.append(v)
         out += _decode_raw_snappy(bytes(varint) + stream[at + 4:at + 4 + csz])
     assert bytes(out) == data
+
+
+def test_converter_to_original_snappy_framing():
+    """tools/to_raw_snappy.py: the whole framed file becomes one stream of the original format."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("to_raw_snappy", os.path.join(ROOT, "tools", "to_raw_snappy.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name in ("alice", "terror2", "plrabn12"):
+        raw = mod.convert(golden_bytes(name + ".snappy"))
+        assert _decode_raw_snappy(raw) == golden_bytes(name + ".txt")
+    for bs in (64, 4096, 65535):
+        data = golden_bytes("coding.txt")
+        assert _decode_raw_snappy(mod.convert(oracle.compress(data, bs))) == data
