@@ -67,7 +67,10 @@ struct program_runtime {
  * Replaces snappy_compress_dpu (snappy_compress.c:487-714).
  * Entry: input->buffer/curr at file start, input->length = n.  output->buffer may be NULL
  * or any malloc'd block; it is realloc'd to the needed size (the reference's
- * 32+n+n/6, snappy_compress.c:446-447, is too small for tiny block sizes).
+ * 32+n+n/6, snappy_compress.c:446-447, is too small for tiny block sizes).  If the caller
+ * sets output->max to a finite capacity (anything but ULONG_MAX, the reference's default,
+ * dpu_snappy.c:112), output->buffer is used as is -- e.g. a page-locked buffer -- and
+ * SNAPPY_BUFFER_TOO_SMALL is returned if the stream does not fit.
  * Exit: framed stream in output->buffer[0..output->length); caller writes the file.
  * Fills every field of *runtime (pre is accumulated with +=, as snappy_compress.c:528).
  * Uses SNAPPY_HIP_NUM_GPUS devices (env, default: all visible), contiguous block ranges
@@ -113,6 +116,11 @@ typedef struct snappy_hip_stream_desc {
 	uint32_t header_len;        /* bytes of the two varints                               */
 	uint32_t num_blocks;        /* ceil(total_len / block_size)                           */
 } snappy_hip_stream_desc;
+
+/* Page-locked host memory for callers that want PCIe-rate copies through the drop-in pair (the CLI reads its
+ * input file straight into such a buffer).  NULL on failure. */
+void *snappy_hip_host_alloc(size_t bytes);
+void snappy_hip_host_free(void *p);
 
 int snappy_hip_device_count(void);
 int snappy_hip_set_device(int device);

@@ -173,6 +173,21 @@ hipError_t set_shard_device(int shard) { return hipSetDevice(shard % g_physical_
 // ===========================================================================
 extern "C" {
 
+void* snappy_hip_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        g_last_error = "hipHostMalloc failed";
+        return nullptr;
+    }
+    return p;
+}
+
+void snappy_hip_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int snappy_hip_device_count(void)
 {
     int n = 0;
@@ -426,6 +441,26 @@ struct DecompressShard {
     bool bad = false;
 };
 
+// "load" phase (dpu_load, snappy_compress.c:541): make the device ready so that the copy and run phases measure
+// copies and kernels -- code object on the device, copy engines and the co-run helper stream initialised.
+int warm_up_device()
+{
+    hipFuncAttributes fa;
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel)));
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_lds_table_kernel)));
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::gather_slots_kernel)));
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel<false>)));
+    CoRunResources* cr = nullptr;
+    if (int rc = corun_resources(&cr)) return rc;
+    uint32_t* c = nullptr;
+    if (int rc = next_work_counter(&c, nullptr)) return rc;      // also touches the module's globals
+    uint32_t probe = 0;
+    HIP_TRY(hipMemcpy(&probe, c, sizeof(probe), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c, &probe, sizeof(probe), hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
 snappy_status report(const char* where, int rc)
 {
     fprintf(stderr, "snappy_hip: %s failed: %s\n", where, g_last_error.c_str());
@@ -495,10 +530,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         HIP_TRY(set_shard_device(g));
-        hipFuncAttributes fa;
-        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel)));
-        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::gather_slots_kernel)));
-        return 0;
+        return warm_up_device();
     });
     runtime->load = now_seconds() - t0;
     if (rc) return report("code object load", rc);
@@ -556,7 +588,16 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
         s.out_off = total;
         if (s.num_blocks) total += s.stream_len - s.local_hdr;
     }
-    {
+    if (output->buffer && output->max != ~0UL) {
+        // caller-owned buffer of stated capacity (e.g. page-locked): use it as is
+        if (total > output->max) {
+            fprintf(stderr, "snappy_hip: output buffer of %lu bytes cannot hold the %lu-byte stream\n", output->max,
+                    (unsigned long)total);
+            return SNAPPY_BUFFER_TOO_SMALL;
+        }
+        output->curr = output->buffer;
+        memcpy(output->buffer, hdr, hdr_len);
+    } else {
         uint8_t* nbuf = (uint8_t*)realloc(output->buffer, total ? total : 1);
         if (!nbuf) {
             fprintf(stderr, "snappy_hip: cannot allocate %lu bytes for the output\n", (unsigned long)total);
@@ -683,9 +724,7 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         HIP_TRY(set_shard_device(g));
-        hipFuncAttributes fa;
-        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel<false>)));
-        return 0;
+        return warm_up_device();
     });
     runtime->load = now_seconds() - t0;
     if (rc) return report("code object load", rc);

@@ -31,6 +31,21 @@ static void usage(const char *exe)                          /* dpu_snappy.c:70-8
 	fprintf(stderr, "o: output file\n");
 }
 
+/* In -d mode the file buffers are page-locked (snappy_hip_host_alloc) so that the copies inside
+ * snappy_*_gpu run at PCIe rate instead of through the driver's pageable bounce buffers. */
+static int g_pinned = 0;
+
+static uint8_t *buffer_alloc(unsigned long bytes)
+{
+	if (g_pinned) {
+		uint8_t *p = snappy_hip_host_alloc(bytes);
+		if (p)
+			return p;
+		g_pinned = 0;                /* no device: -d will fail loudly later; keep going with malloc */
+	}
+	return malloc(bytes ? bytes : 8);
+}
+
 static int slurp(const char *path, struct host_buffer_context *in)    /* dpu_snappy.c:23-50 */
 {
 	FILE *f = fopen(path, "rb");
@@ -47,7 +62,7 @@ static int slurp(const char *path, struct host_buffer_context *in)    /* dpu_sna
 		return 1;
 	}
 	in->length = (unsigned long)sz;
-	in->buffer = malloc(((unsigned long)sz + 7) & ~7UL ? (((unsigned long)sz + 7) & ~7UL) : 8);
+	in->buffer = buffer_alloc(((unsigned long)sz + 7) & ~7UL);
 	in->curr = in->buffer;
 	size_t got = fread(in->buffer, 1, in->length, f);
 	fclose(f);
@@ -107,6 +122,7 @@ int main(int argc, char **argv)
 	output.file_name = out_path;
 	printf("Using output file %s\n", out_path);
 
+	g_pinned = use_gpu;
 	if (slurp(in_path, &input))
 		return -1;
 
@@ -115,7 +131,18 @@ int main(int argc, char **argv)
 	snappy_status st;
 	struct timeval t0, t1;
 	if (compress) {
-		setup_compression(&input, &output, &rt);
+		if (use_gpu && g_pinned && block_size >= 1 && block_size <= 65535) {
+			/* page-locked output of the stream's upper bound; max = capacity tells the library not to realloc */
+			struct timeval a, b;
+			gettimeofday(&a, NULL);
+			output.max = snappy_hip_stream_bound(input.length, (uint32_t)block_size);
+			output.buffer = buffer_alloc(output.max);
+			output.curr = output.buffer;
+			gettimeofday(&b, NULL);
+			rt.pre = get_runtime(&a, &b);
+		} else {
+			setup_compression(&input, &output, &rt);
+		}
 		if (use_gpu) {
 			st = snappy_compress_gpu(&input, &output, (uint32_t)block_size, &rt);
 		} else {
@@ -127,6 +154,11 @@ int main(int argc, char **argv)
 	} else {
 		if (setup_decompression(&input, &output, &rt))
 			return -1;
+		if (use_gpu && g_pinned) {           /* swap the malloc'd plaintext buffer for a page-locked one */
+			free(output.buffer);
+			output.buffer = buffer_alloc((output.length + 7) & ~7UL);
+			output.curr = output.buffer;
+		}
 		if (use_gpu) {
 			st = snappy_decompress_gpu(&input, &output, &rt);
 		} else {
