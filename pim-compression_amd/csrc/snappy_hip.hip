@@ -97,6 +97,10 @@ int for_each_device(int count, const std::function<int(int)>& fn)
 
 constexpr int kVariantLdsTable = 1, kVariantGlobalTable = 3, kVariantLanePerBlock = 4, kVariantGroup = 5;
 constexpr int kDefaultDecompressVariant = 1;   // the concurrent LDS+global form (2) measured no faster for K2
+constexpr int kDefaultK1Ahead = 64;     // look-ahead of the global-table form (64 = the whole cursor window)
+constexpr int kDefaultK1AheadLds = 64;  // look-ahead of the LDS-table form
+constexpr int kDefaultK1Form = 0;
+constexpr int kDefaultK1FormLds = 0;
 constexpr int kDefaultLdsWaves = 1024;   // 4 LDS-table wavefronts per CU beside 28 global-table ones (measured best)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 
@@ -165,6 +169,42 @@ int requested_gpus()
 }
 
 hipError_t set_shard_device(int shard) { return hipSetDevice(shard % g_physical_devices); }
+
+// K1 launchers.  SNAPPY_HIP_K1_AHEAD[_LDS] = look-ahead width of the speculative table reads (0 = serial probes only);
+// SNAPPY_HIP_K1_FORM[_LDS] = 1 selects the masked form (lane-mask resolution of the probes), 2 the bulk form
+// (per-segment table commit and emission); both need a look-ahead >= 16.
+template <uint32_t kAhead, int kForm>
+void launch_k1_global(uint32_t grid, hipStream_t st, const uint8_t* d_in, uint64_t input_len, uint32_t block_size, uint8_t* d_slots,
+                      uint32_t slot_stride, uint32_t* d_block_bytes, uint32_t nb, uint32_t* tables, uint32_t* counter)
+{
+    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<kAhead, kForm>), dim3(grid), dim3(64), 0, st, d_in,
+                       input_len, block_size, d_slots, slot_stride, d_block_bytes, nb, tables, counter);
+}
+template <uint32_t kAhead, int kForm>
+void launch_k1_lds(uint32_t grid, uint32_t lds, hipStream_t st, const uint8_t* d_in, uint64_t input_len, uint32_t block_size,
+                   uint8_t* d_slots, uint32_t slot_stride, uint32_t* d_block_bytes, uint32_t nb, uint32_t* counter)
+{
+    hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<kAhead, kForm>), dim3(grid), dim3(64), lds, st, d_in,
+                       input_len, block_size, d_slots, slot_stride, d_block_bytes, nb, counter);
+}
+#define SNAPPY_K1_DISPATCH(fn, ahead, form, ...)                \
+    do {                                                        \
+        if ((form) == 2) {                                      \
+            if ((ahead) >= 64) fn<64, 2>(__VA_ARGS__);          \
+            else if ((ahead) >= 32) fn<32, 2>(__VA_ARGS__);     \
+            else fn<16, 2>(__VA_ARGS__);                        \
+        } else if ((form) == 1) {                               \
+            if ((ahead) >= 64) fn<64, 1>(__VA_ARGS__);          \
+            else if ((ahead) >= 32) fn<32, 1>(__VA_ARGS__);     \
+            else fn<16, 1>(__VA_ARGS__);                        \
+        } else {                                                \
+            if ((ahead) >= 64) fn<64, 0>(__VA_ARGS__);          \
+            else if ((ahead) >= 32) fn<32, 0>(__VA_ARGS__);     \
+            else if ((ahead) >= 16) fn<16, 0>(__VA_ARGS__);     \
+            else if ((ahead) >= 8) fn<8, 0>(__VA_ARGS__);       \
+            else fn<0, 0>(__VA_ARGS__);                         \
+        }                                                       \
+    } while (0)
 
 }  // namespace
 
@@ -265,6 +305,10 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
         (!d_scratch || scratch_bytes < snappy_hip_compress_scratch_bytes() || ((uintptr_t)d_scratch & 255)))
         variant = kVariantLdsTable;   // no scratch: LDS-table kernel (still on the GPU)
     const uint32_t lds = (uint32_t)env_int("SNAPPY_HIP_EXTRA_LDS", 0);
+    const int k1_ahead = env_int("SNAPPY_HIP_K1_AHEAD", kDefaultK1Ahead);
+    const int k1_ahead_lds = env_int("SNAPPY_HIP_K1_AHEAD_LDS", kDefaultK1AheadLds);
+    const int k1_masked = env_int("SNAPPY_HIP_K1_FORM", kDefaultK1Form);          // 0 windowed, 1 masked, 2 bulk
+    const int k1_masked_lds = env_int("SNAPPY_HIP_K1_FORM_LDS", kDefaultK1FormLds);
     const dim3 grid((uint32_t)nb), block(64);
     hipStream_t st = (hipStream_t)stream;
     if (variant == kVariantGroup) {
@@ -298,8 +342,8 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
         hipLaunchKernelGGL(snappy_hip::compress_blocks_lane_kernel, dim3((uint32_t)((nb * rep + 63) / 64)), block, 0, st, d_in,
                            input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, lane_tables, rep);
     } else if (variant == kVariantLdsTable) {
-        hipLaunchKernelGGL(snappy_hip::compress_blocks_lds_table_kernel, grid, block, lds, st, d_in, input_len, block_size,
-                           d_slots, slot_stride, d_block_bytes, (uint32_t)nb, (uint32_t*)nullptr);
+        SNAPPY_K1_DISPATCH(launch_k1_lds, k1_ahead_lds, k1_masked_lds, (uint32_t)nb, lds, st, d_in, input_len, block_size, d_slots, slot_stride,
+                           d_block_bytes, (uint32_t)nb, (uint32_t*)nullptr);
     } else {
         // persistent grid, blocks handed out by an atomic counter kept in the first bytes of the scratch
         uint32_t waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", kGlobalTableWaves);
@@ -320,15 +364,15 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
             hipEvent_t ev_begin = cr->ev_begin, ev_end = cr->ev_end;
             HIP_TRY(hipEventRecord(ev_begin, st));                     // after the counter memset and all prior work
             HIP_TRY(hipStreamWaitEvent(helper, ev_begin, 0));
-            hipLaunchKernelGGL(snappy_hip::compress_blocks_lds_table_kernel, dim3(lds_waves), block, 0, helper, d_in, input_len,
-                               block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, counter);
+            SNAPPY_K1_DISPATCH(launch_k1_lds, k1_ahead_lds, k1_masked_lds, lds_waves, 0u, helper, d_in, input_len, block_size, d_slots, slot_stride,
+                               d_block_bytes, (uint32_t)nb, counter);
             HIP_TRY(hipEventRecord(ev_end, helper));
-            hipLaunchKernelGGL(snappy_hip::compress_blocks_global_table_kernel, dim3(g), block, 0, st, d_in, input_len,
-                               block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);
+            SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride, d_block_bytes,
+                               (uint32_t)nb, tables, counter);
             HIP_TRY(hipStreamWaitEvent(st, ev_end, 0));                // the caller's stream resumes when both are done
         } else {
-            hipLaunchKernelGGL(snappy_hip::compress_blocks_global_table_kernel, dim3(g), block, 0, st, d_in, input_len,
-                               block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);
+            SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride, d_block_bytes,
+                               (uint32_t)nb, tables, counter);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -446,8 +490,8 @@ struct DecompressShard {
 int warm_up_device()
 {
     hipFuncAttributes fa;
-    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel)));
-    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_lds_table_kernel)));
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel<0, 0>)));
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_lds_table_kernel<0, 0>)));
     HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::gather_slots_kernel)));
     HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel<false>)));
     CoRunResources* cr = nullptr;

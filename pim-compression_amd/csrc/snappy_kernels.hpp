@@ -221,9 +221,9 @@ struct CursorWindow {
         x1 = load_at(base + 64, lane);
     }
     // make `pos` fall inside [base, base + 64)
-    __device__ __forceinline__ void ensure(uint32_t pos, uint32_t lane)
+    __device__ __forceinline__ bool ensure(uint32_t pos, uint32_t lane)   // true when the window moved
     {
-        if (pos < base + 64) return;
+        if (pos < base + 64) return false;
         if (pos < base + 128) {
             base += 64;
             x0 = x1;
@@ -233,6 +233,7 @@ struct CursorWindow {
         } else {
             reset(pos, lane);
         }
+        return true;
     }
     __device__ __forceinline__ uint32_t bytes_at(uint32_t pos) const   // pos in [base, base+64)
     {
@@ -311,6 +312,9 @@ struct TaggedGlobalTable {      // u32 entries in the global scratch: tag << 16 
     }
     // true when the candidate stored in `old` can be skipped without looking at its bytes
     __device__ __forceinline__ static bool certain_miss(uint32_t old, uint32_t entry) { return ((old ^ entry) >> 16) != 0; }
+    // per-lane (divergent index) accessors for the look-ahead gather
+    __device__ __forceinline__ uint32_t load_lane(uint32_t h) const { return t[h]; }
+    __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const { t[h] = entry; }
 };
 
 struct LdsTable {               // the reference's own layout: u16 positions, in LDS (no room for tags: 32 KiB per block)
@@ -333,6 +337,8 @@ struct LdsTable {               // the reference's own layout: u16 positions, in
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ static bool certain_miss(uint32_t, uint32_t) { return false; }
+    __device__ __forceinline__ uint32_t load_lane(uint32_t h) const { return t[h]; }
+    __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const { t[h] = (uint16_t)entry; }
 };
 
 // Emitters of the windowed form.  Element headers are packed into one dword and stored by a single lane
@@ -380,7 +386,83 @@ __device__ __forceinline__ uint32_t emit_literal_windowed(uint8_t* __restrict__ 
     return op + hdr + len;
 }
 
-template <class Table>
+// Speculative table-entry cache of the windowed form ("look-ahead").  The hash of every position in the cursor window is
+// already in a register, so the table slots the parse MAY probe next are known before it gets there.  When a probe lands on
+// a window lane whose slot has not been read yet, lanes r .. r+kAhead-1 read their slots in ONE gather (`ent`), and the
+// lanes whose tag matches read their 12 candidate bytes in a second (`k0..k2`, `kmask`).  Later probes inside the covered
+// range take entry and candidate bytes from registers: a chain of short matches or a scan run costs two memory round trips
+// per kAhead positions instead of two per probe.  The cached entries are kept equal to the table: every table write
+// (probe inserts, :347/:397, and the post-match insert, :391-392) also overwrites `ent` in the lanes that hash to the
+// written slot, and drops their cached candidate bytes (`kmask`), which belong to the previous occupant.
+// A probe therefore sees exactly the entry the reference's sequential table would hold.
+template <class Table, uint32_t kAhead>
+struct EntryCache {
+    uint32_t ent = 0;                 // per lane: table[h0] as of now, valid for lanes in [.., cov_end)
+    uint32_t k0 = 0, k1 = 0, k2 = 0;  // per lane: 12 bytes at (ent & 0xffff), valid where kmask has the lane's bit
+    unsigned long long kmask = 0;     // wave-uniform
+    uint32_t cov_end = 0;             // wave-uniform: window lanes below this have a valid `ent` (lanes behind ip are dead)
+
+    __device__ __forceinline__ void invalidate()
+    {
+        cov_end = 0;
+        kmask = 0;
+    }
+    // read slots for lanes [r, r+span) of the window (clipped at 64), and candidate bytes where the tag allows a hit
+    __device__ __forceinline__ void gather(const Table& table, const CursorWindow& win, uint32_t r, uint32_t span,
+                                           uint32_t lane)
+    {
+        const bool g = lane >= r && lane < r + span;
+        if (g) ent = table.load_lane(win.h0);
+        const uint32_t mine_l = win.e0 | (win.base + lane);
+        const bool worth = g && !Table::certain_miss(ent, mine_l);
+        if (worth) {                                  // every stored position p has p + 16 <= block length
+            const uint8_t* __restrict__ c = win.blk + (ent & 0xffffu);
+            k0 = ld32(c);
+            k1 = ld32(c + 4);
+            k2 = ld32(c + 8);
+        }
+        kmask = __ballot(worth);                      // lanes outside [r, r+span) are dead or not yet covered
+        cov_end = (r + span < kWave) ? r + span : kWave;
+    }
+    // the table slot `h` now holds `entry`
+    __device__ __forceinline__ void wrote(const CursorWindow& win, uint32_t h, uint32_t entry)
+    {
+        const bool same = win.h0 == h;
+        ent = same ? entry : ent;
+        kmask &= ~__ballot(same);
+    }
+};
+
+// One probe (:344-348 / :393-398) at `ip`, which must be inside the window: returns the previous table entry, inserts
+// `ip`, and reports whether the 4 bytes at the candidate equal `cur`; on a hit `cb` holds the candidate's 12 bytes.
+template <class Table, uint32_t kAhead>
+__device__ __forceinline__ bool probe_cached(const Table& table, EntryCache<Table, kAhead>& ec, const CursorWindow& win,
+                                             const uint8_t* __restrict__ base16, uint64_t start, uint32_t ip, uint32_t cur,
+                                             uint32_t span, uint32_t lane, uint32_t& cand, CandidateBytes& cb)
+{
+    const uint32_t r = ip - win.base;
+    const uint32_t h = win.hash_at(ip);
+    const uint32_t mine = win.entry_at(ip);
+    if (r >= ec.cov_end) ec.gather(table, win, r, span, lane);
+    const uint32_t old = (uint32_t)__builtin_amdgcn_readlane((int)ec.ent, (int)r);
+    const bool cached_bytes = (ec.kmask >> r) & 1ull;     // before wrote() clears lane r's own bit
+    table.put(h, mine, lane);
+    ec.wrote(win, h, mine);
+    cand = old & 0xffffu;
+    if (Table::certain_miss(old, mine)) return false;
+    if (cached_bytes) {
+        cb.c0 = (uint32_t)__builtin_amdgcn_readlane((int)ec.k0, (int)r);
+        if (cb.c0 != cur) return false;
+        cb.c1 = (uint32_t)__builtin_amdgcn_readlane((int)ec.k1, (int)r);
+        cb.c2 = (uint32_t)__builtin_amdgcn_readlane((int)ec.k2, (int)r);
+        return true;
+    }
+    cb.fetch(base16, start + cand);                        // the slot was rewritten after the gather
+    return cb.c0 == cur;
+}
+
+// kAhead > 0 enables the speculative entry cache above; 0 is the plain serial probe.
+template <class Table, uint32_t kAhead = 0>
 __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __restrict__ base16, uint64_t start,
                                                             uint64_t in_len, uint32_t n, uint8_t* __restrict__ dst,
                                                             const Table table, uint32_t lane,
@@ -408,6 +490,7 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
         win.avail = (left < 0x7fffffffull) ? (uint32_t)left : 0x7fffffffu;
         win.shift = shift;
         win.reset(0, lane);
+        EntryCache<Table, kAhead> ec;
         uint32_t ip = 1;      // :305
         for (;;) {
             // ---- step 1: scan for a 4-byte match (:333-348) ----
@@ -416,19 +499,27 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
             CandidateBytes cb;
             bool hit = false;
             for (;;) {
-                win.ensure(ip, lane);
+                if (win.ensure(ip, lane) && kAhead) ec.invalidate();
                 const uint32_t cur = win.bytes_at(ip);
-                const uint32_t h = win.hash_at(ip);
-                const uint32_t next_ip = ip + (skip++ >> 5);
+                const uint32_t stride = skip++ >> 5;
+                const uint32_t next_ip = ip + stride;
                 if (next_ip > limit) break;     // :342-343, before touching the table
-                const uint32_t mine = win.entry_at(ip);
-                const uint32_t old = table.exchange(h, mine, lane);
-                cand = old & 0xffffu;
-                if (!Table::certain_miss(old, mine)) {           // same tag: only now are the bytes worth fetching
-                    cb.fetch(base16, start + cand);
-                    if (cur == cb.c0) {
-                        hit = true;
-                        break;
+                if (kAhead) {
+                    // look ahead only while the scan moves one position at a time (:339); wider strides probe one slot
+                    hit = probe_cached<Table, kAhead>(table, ec, win, base16, start, ip, cur, stride == 1 ? kAhead : 1u, lane,
+                                                      cand, cb);
+                    if (hit) break;
+                } else {
+                    const uint32_t h = win.hash_at(ip);
+                    const uint32_t mine = win.entry_at(ip);
+                    const uint32_t old = table.exchange(h, mine, lane);
+                    cand = old & 0xffffu;
+                    if (!Table::certain_miss(old, mine)) {           // same tag: only now are the bytes worth fetching
+                        cb.fetch(base16, start + cand);
+                        if (cur == cb.c0) {
+                            hit = true;
+                            break;
+                        }
                     }
                 }
                 ip = next_ip;
@@ -458,16 +549,25 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
                     done = true;
                     break;
                 }
-                win.ensure(ip - 1, lane);
-                table.put(win.hash_at(ip - 1), win.entry_at(ip - 1), lane);   // :391-392
-                win.ensure(ip, lane);
+                if (win.ensure(ip - 1, lane) && kAhead) ec.invalidate();
+                {
+                    const uint32_t hp = win.hash_at(ip - 1);
+                    const uint32_t ep = win.entry_at(ip - 1);
+                    table.put(hp, ep, lane);                                  // :391-392
+                    if (kAhead) ec.wrote(win, hp, ep);
+                }
+                if (win.ensure(ip, lane) && kAhead) ec.invalidate();
                 const uint32_t here = win.bytes_at(ip);
-                const uint32_t mine_e = win.entry_at(ip);
-                const uint32_t old = table.exchange(win.hash_at(ip), mine_e, lane);   // :394-397
-                cand = old & 0xffffu;
-                if (Table::certain_miss(old, mine_e)) break;   // different tag: certain miss (:398)
-                cb.fetch(base16, start + cand);
-                if (here != cb.c0) break;                  // :396,:398
+                if (kAhead) {
+                    if (!probe_cached<Table, kAhead>(table, ec, win, base16, start, ip, here, kAhead, lane, cand, cb)) break;
+                } else {
+                    const uint32_t mine_e = win.entry_at(ip);
+                    const uint32_t old = table.exchange(win.hash_at(ip), mine_e, lane);   // :394-397
+                    cand = old & 0xffffu;
+                    if (Table::certain_miss(old, mine_e)) break;   // different tag: certain miss (:398)
+                    cb.fetch(base16, start + cand);
+                    if (here != cb.c0) break;                  // :396,:398
+                }
             }
             if (done) break;
             ++ip;                                                // :400-401
@@ -483,9 +583,490 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---------------------------------------------------------------------------
+// K1, masked form.  The PMC profile of the look-ahead form above shows it instruction-issue bound (SQ_WAIT_INST_ANY +
+// SQ_ACTIVE_INST_ANY > 50 % of wave cycles, ~80 instructions per probe).  This form keeps the same speculative gather but
+// resolves the probes of a window with 64-bit lane masks instead of one scalar round per probe:
+//
+//  * gather(r): lanes r .. r+kChunk-1 read their table slot, the tag-matching ones their 12 candidate bytes, and every
+//    lane computes -- in parallel -- whether a probe at its position WOULD hit (HIT mask, :348 / :398) and how many of the
+//    next 8 bytes would match (`extv`, the head of find_match_length, :176-193).
+//  * The speculation is valid for a lane as long as no insert made after the gather went to its table slot.  Inserts
+//    between a window's gather and the probe of one of its lanes are all positions of that same window, so the lanes at
+//    risk are exactly those that share a slot with another lane of the window.  dup_slot_lanes() finds a superset of them
+//    (DUP mask) with four LDS byte accesses; DUP lanes never use the cache: they take the serial exchange below.
+//  * A scan run (:336-348, stride 1) is then: first set bit of (HIT | DUP) at or above the cursor.  The misses in front of
+//    it are committed with ONE masked vector store (each lane writes its own entry to its own slot -- distinct slots, so
+//    the order the reference made them in does not matter), and a resolved hit costs two v_readlane.
+// Decisions, table contents after every step, and output bytes are those of snappy_compress.c:284-413.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kDupSlots = 1024;   // bytes of LDS per wavefront for the duplicate-slot test
+#ifdef SNAPPY_EMU
+typedef volatile uint8_t* lds_bytes_t;
+#else
+typedef volatile __attribute__((address_space(3))) uint8_t* lds_bytes_t;   // keeps the accesses ds_*, not flat_*
+#endif
+
+__device__ __forceinline__ uint32_t ctz64_or(unsigned long long x, uint32_t if_zero)
+{
+    return x ? (uint32_t)__builtin_ctzll(x) : if_zero;
+}
+// lanes [lo, lo + cnt), 1 <= cnt, lo + cnt <= 64
+__device__ __forceinline__ unsigned long long lane_range(uint32_t lo, uint32_t cnt)
+{
+    return (~0ull >> (64u - cnt)) << lo;
+}
+
+// Superset of the lanes whose table slot `h` is shared with another lane: lanes race for a byte per slot; every loser, and
+// every winner that a loser then marks, is reported.  (A slot group of one reads back its own lane id twice.)
+__device__ __forceinline__ unsigned long long dup_slot_lanes(lds_bytes_t scratch, uint32_t h, uint32_t lane)
+{
+    const uint32_t slot = h & (kDupSlots - 1);
+    scratch[slot] = (uint8_t)lane;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t winner = scratch[slot];
+    __builtin_amdgcn_wave_barrier();
+    if (winner != lane) scratch[slot] = 0xff;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t mark = scratch[slot];
+    __builtin_amdgcn_wave_barrier();
+    return __ballot(mark == 0xff);
+}
+
+template <class Table, uint32_t kChunk>
+struct MaskedWindowState {
+    uint32_t ent = 0;               // per lane: table slot content at gather time
+    uint32_t extv = 0;              // per lane: matching bytes among the 8 after the 4-byte key (0..8), for HIT lanes
+    unsigned long long hit = 0;     // wave-uniform: lanes whose probe would hit
+    unsigned long long dup = 0;     // wave-uniform: lanes that must not use the cache
+    unsigned long long longm = 0;   // wave-uniform: HIT lanes with extv == 8
+    uint32_t cov_end = 0;           // lanes in [gather start, cov_end) are resolved
+    bool dup_valid = false;
+
+    __device__ __forceinline__ void invalidate()
+    {
+        cov_end = 0;
+        hit = 0;
+        dup_valid = false;
+    }
+
+    // le32(block + window base + lane + d), d in {4, 8}: from the current or the prefetched granule
+    __device__ __forceinline__ static uint32_t bytes_ahead(const CursorWindow& win, uint32_t lane, uint32_t d)
+    {
+        const uint32_t src = (lane + d) & 63u;
+        const uint32_t a = (uint32_t)__shfl((int)win.x0, (int)src);
+        const uint32_t b = (uint32_t)__shfl((int)win.x1, (int)src);
+        return (lane + d < kWave) ? a : b;
+    }
+
+    __device__ __forceinline__ void gather(const Table& table, const CursorWindow& win, lds_bytes_t scratch, uint32_t r,
+                                           uint32_t span, uint32_t lane)
+    {
+        if (!dup_valid) {
+            dup = dup_slot_lanes(scratch, win.h0, lane);
+            dup_valid = true;
+        }
+        const uint32_t e = (r + span < kWave) ? r + span : kWave;
+        const unsigned long long gm = lane_range(r, e - r) & ~dup;
+        const bool g = __builtin_amdgcn_inverse_ballot_w64(gm);
+        if (g) ent = table.load_lane(win.h0);
+        const uint32_t mine_l = win.e0 | (win.base + lane);
+        const bool worth = g && !Table::certain_miss(ent, mine_l);
+        uint32_t k0 = 0, k1 = 0, k2 = 0;
+        if (worth) {                                  // every stored position p has p + 16 <= block length
+            const uint8_t* __restrict__ c = win.blk + (ent & 0xffffu);
+            k0 = ld32(c);
+            k1 = ld32(c + 4);
+            k2 = ld32(c + 8);
+        }
+        const uint32_t xa = bytes_ahead(win, lane, 4);
+        const uint32_t xb = bytes_ahead(win, lane, 8);
+        const uint32_t d0 = k1 ^ xa, d1 = k2 ^ xb;
+        extv = d0 ? ((uint32_t)__builtin_ctz(d0) >> 3) : (d1 ? 4u + ((uint32_t)__builtin_ctz(d1) >> 3) : 8u);
+        const bool hitl = worth && k0 == win.x0;
+        hit = __ballot(hitl);                          // lanes below r are behind the cursor, lanes >= e not covered
+        longm = __ballot(hitl && extv == 8);           // hits whose match goes on past 12 bytes
+        cov_end = e;
+    }
+
+    // insert the positions of the lanes in `m` (each its own slot)
+    __device__ __forceinline__ static void commit(const Table& table, const CursorWindow& win, unsigned long long m, uint32_t lane)
+    {
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) table.store_lane(win.h0, win.e0 | (win.base + lane));
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+// first 8 bytes of find_match_length (:176-193) on the scalar side, for a probe resolved by the serial exchange
+__device__ __forceinline__ uint32_t ext_from_candidate(const CursorWindow& win, uint32_t ip, const CandidateBytes& cb)
+{
+    const uint64_t mine = (uint64_t)win.bytes_near(ip + 4) | ((uint64_t)win.bytes_near(ip + 8) << 32);
+    const uint64_t diff = mine ^ cb.next8();
+    return diff ? ((uint32_t)__builtin_ctzll(diff) >> 3) : 8u;
+}
+
+template <class Table, uint32_t kChunk>
+__device__ __forceinline__ void compress_one_block_masked(const uint8_t* __restrict__ base16, uint64_t start, uint64_t in_len,
+                                                          uint32_t n, uint8_t* __restrict__ dst, const Table table,
+                                                          uint32_t lane, uint32_t* __restrict__ block_bytes_out,
+                                                          lds_bytes_t dup_scratch)
+{
+    using State = MaskedWindowState<Table, kChunk>;
+    const uint8_t* __restrict__ blk = base16 + start;
+    const uint32_t ts = table_entries_for(n);                    // get_hash_table, :139-146 (+ shift, :288)
+    const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
+    if (n >= kInputMargin) {
+        const uint32_t e_zero = ((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u;
+        table.init(ts, e_zero, lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t op = 4;          // :291
+    uint32_t next_emit = 0;   // :298
+
+    if (n >= kInputMargin) {  // :301
+        const uint32_t limit = n - kInputMargin;
+        const uint64_t left = in_len - start;
+        CursorWindow win;
+        win.blk = blk;
+        win.avail = (left < 0x7fffffffull) ? (uint32_t)left : 0x7fffffffu;
+        win.shift = shift;
+        win.reset(0, lane);
+        State st;
+        uint32_t ip = 1;      // :305
+        for (;;) {
+            // ---- step 1: scan for a 4-byte match (:333-348) ----
+            uint32_t skip = 32;
+            uint32_t cand = 0, ext = 0;
+            bool hit = false;
+            for (;;) {
+                const uint32_t stride = skip >> 5;
+                if (ip + stride > limit) break;                  // :342-343, before touching the table
+                if (win.ensure(ip, lane)) st.invalidate();
+                uint32_t r = ip - win.base;
+                if (r >= uni(st.cov_end)) st.gather(table, win, dup_scratch, r, stride == 1 ? kChunk : 1u, lane);
+                bool serial = true;
+                if (stride == 1) {
+                    // lanes [r, hi): resolved, probed one position apart, and allowed by :342 (position + 1 <= limit)
+                    uint32_t hi = uni(st.cov_end);
+                    const uint32_t budget = r + (64u - skip);    // the stride becomes 2 once skip reaches 64 (:339)
+                    hi = budget < hi ? budget : hi;
+                    const uint32_t lim = limit - win.base;
+                    hi = lim < hi ? lim : hi;
+                    const uint32_t run = hi - r;                 // >= 1
+                    const uint32_t f0 = ctz64_or((st.hit | st.dup) >> r, 64u);
+                    const uint32_t f = f0 < run ? f0 : run;      // plain misses in front of the first hit / DUP lane
+                    if (f) {
+                        State::commit(table, win, lane_range(r, f), lane);
+                        ip += f;
+                        skip += f;
+                    }
+                    if (f == run) continue;                      // coverage, stride-1 budget or limit ran out: re-evaluate
+                    r += f;
+                    serial = (st.dup >> r) & 1ull;
+                    if (!serial) {                               // a resolved hit
+                        State::commit(table, win, 1ull << r, lane);
+                        cand = (uint32_t)__builtin_amdgcn_readlane((int)st.ent, (int)r) & 0xffffu;
+                        ext = (uint32_t)__builtin_amdgcn_readlane((int)st.extv, (int)r);
+                        hit = true;
+                        break;
+                    }
+                } else {
+                    serial = (st.dup >> r) & 1ull;
+                    if (!serial) {
+                        State::commit(table, win, 1ull << r, lane);
+                        if ((st.hit >> r) & 1ull) {
+                            cand = (uint32_t)__builtin_amdgcn_readlane((int)st.ent, (int)r) & 0xffffu;
+                            ext = (uint32_t)__builtin_amdgcn_readlane((int)st.extv, (int)r);
+                            hit = true;
+                            break;
+                        }
+                        ip += stride;
+                        ++skip;
+                        continue;
+                    }
+                }
+                // serial probe: this lane shares its table slot with another lane of the window, ask the table itself
+                {
+                    const uint32_t cur = win.bytes_at(ip);
+                    const uint32_t mine = win.entry_at(ip);
+                    const uint32_t old = table.exchange(win.hash_at(ip), mine, lane);
+                    cand = old & 0xffffu;
+                    if (!Table::certain_miss(old, mine)) {
+                        CandidateBytes cb;
+                        cb.fetch(base16, start + cand);
+                        if (cur == cb.c0) {
+                            ext = ext_from_candidate(win, ip, cb);
+                            hit = true;
+                            break;
+                        }
+                    }
+                    ip += skip >> 5;
+                    ++skip;
+                }
+            }
+            if (!hit) break;
+
+            // ---- step 2: literal run [next_emit, ip) (:355); ip is inside the window ----
+            op = emit_literal_windowed(dst, op, blk, next_emit, ip - next_emit, win.base, win.x0, lane);
+
+            // ---- step 3: copy chain (:370-398) ----
+            bool done = false;
+            for (;;) {
+                const uint32_t mbase = ip;
+                uint32_t matched = 4 + ext;                      // find_match_length (:176-193)
+                if (ext == 8) matched = 12 + match_extend(blk, cand + 12, ip + 12, n, lane);
+                ip += matched;
+                op = emit_copy_packed(dst, op, mbase - cand, matched, lane);
+                next_emit = ip;
+                if (ip >= limit) {                               // :388-389
+                    done = true;
+                    break;
+                }
+                if (win.ensure(ip - 1, lane)) st.invalidate();
+                State::commit(table, win, 1ull << (ip - 1 - win.base), lane);   // :391-392
+                if (win.ensure(ip, lane)) st.invalidate();
+                const uint32_t r = ip - win.base;
+                if (r >= uni(st.cov_end)) st.gather(table, win, dup_scratch, r, kChunk, lane);
+                if (!((st.dup >> r) & 1ull)) {                   // :393-398 from the cache
+                    State::commit(table, win, 1ull << r, lane);
+                    if (!((st.hit >> r) & 1ull)) break;
+                    cand = (uint32_t)__builtin_amdgcn_readlane((int)st.ent, (int)r) & 0xffffu;
+                    ext = (uint32_t)__builtin_amdgcn_readlane((int)st.extv, (int)r);
+                } else {
+                    const uint32_t here = win.bytes_at(ip);
+                    const uint32_t mine_e = win.entry_at(ip);
+                    const uint32_t old = table.exchange(win.hash_at(ip), mine_e, lane);
+                    cand = old & 0xffffu;
+                    if (Table::certain_miss(old, mine_e)) break;
+                    CandidateBytes cb;
+                    cb.fetch(base16, start + cand);
+                    if (here != cb.c0) break;
+                    ext = ext_from_candidate(win, ip, cb);
+                }
+            }
+            if (done) break;
+            ++ip;                                                // :400-401
+        }
+    }
+
+    // emit_remainder (:405-410) and the size prefix (:412)
+    if (next_emit < n) op = emit_literal(dst, op, blk + next_emit, n - next_emit, lane);
+    if (lane == 0) {
+        st32(dst, op - 4);
+        *block_bytes_out = op;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------
+// K1, bulk form: the masked form with the per-match work moved off the scalar chain.  Within one window, for as long as
+// the parse only meets resolved lanes (not DUP), short matches (< 12 bytes, length known from `extv`) and stride-1
+// scanning, the walk is pure mask arithmetic -- per match: first set bit of HIT above the cursor, one v_readlane for the
+// match length, four mask updates.  What the reference does per step is then done once per such SEGMENT by all lanes:
+//   * table inserts (:346-347, :391-392, :397): one masked vector store for every probed lane and every "ip - 1" lane;
+//   * emission (:355, :202-245): each lane derives its own output offset from the segment's masks with v_mbcnt --
+//       P(l) = op + #literal bytes + 2 * #copies + #3-byte copies + #literal headers   (all counted below lane l)
+//     literal lanes store their byte, run-start lanes the literal header, hit lanes the 2- or 3-byte copy element.
+// Anything else (DUP lanes, matches of 12+ bytes, strides > 1, window edges) ends the segment and takes the masked form's
+// single-step path.  Same decisions, same table contents at every read, same bytes as snappy_compress.c:284-413.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t add)
+{
+    return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, add));
+}
+
+template <class Table, uint32_t kChunk>
+__device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restrict__ base16, uint64_t start, uint64_t in_len,
+                                                        uint32_t n, uint8_t* __restrict__ dst, const Table table, uint32_t lane,
+                                                        uint32_t* __restrict__ block_bytes_out, lds_bytes_t dup_scratch)
+{
+    using State = MaskedWindowState<Table, kChunk>;
+    const uint8_t* __restrict__ blk = base16 + start;
+    const uint32_t ts = table_entries_for(n);                    // get_hash_table, :139-146 (+ shift, :288)
+    const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
+    if (n >= kInputMargin) {
+        const uint32_t e_zero = ((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u;
+        table.init(ts, e_zero, lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t op = 4;          // :291
+    uint32_t next_emit = 0;   // :298
+
+    if (n >= kInputMargin) {  // :301
+        const uint32_t limit = n - kInputMargin;
+        const uint64_t left = in_len - start;
+        CursorWindow win;
+        win.blk = blk;
+        win.avail = (left < 0x7fffffffull) ? (uint32_t)left : 0x7fffffffu;
+        win.shift = shift;
+        win.reset(0, lane);
+        State st;
+        uint32_t ip = 1;      // :305
+        // `skip` is the reference's counter (:333, :339) for scan probes; 31 marks "the next probe is the one right after
+        // a copy" (:393-398), which moves on by one position like a stride-1 scan probe and leaves skip = 32 behind.
+        uint32_t skip = 32;
+        for (;;) {
+            const uint32_t stride = skip >> 5;
+            const uint32_t step = stride ? stride : 1u;
+            if (ip + step > limit) break;                        // :342-343 / :388-389
+            if (win.ensure(ip, lane)) st.invalidate();
+            uint32_t r = ip - win.base;
+            if (r >= uni(st.cov_end)) st.gather(table, win, dup_scratch, r, stride <= 1 ? kChunk : 1u, lane);
+            const unsigned long long stop = st.dup | st.longm;
+
+            if (stride <= 1 && !((stop >> r) & 1ull)) {
+                // ---------------- segment walk ----------------
+                uint32_t hi = uni(st.cov_end);
+                const uint32_t lim = limit - win.base;           // lanes below may be probed (position + 1 <= limit)
+                hi = lim < hi ? lim : hi;
+                const unsigned long long interesting = st.hit | stop;
+                unsigned long long H = 0, VIS = 0, INS = 0, COV = 0;
+                uint32_t first_hit = 64, last_end = 0;
+                uint32_t budget = 64u - skip;                    // stride-1 probes left before :339 widens the stride
+                bool done = false, insert_pending = false;
+                for (;;) {
+                    uint32_t run = (r + budget < hi ? r + budget : hi);
+                    if (run <= r) break;                         // coverage, limit or stride-1 budget used up
+                    run -= r;
+                    const uint32_t f0 = ctz64_or(interesting >> r, 64u);
+                    const uint32_t f = f0 < run ? f0 : run;      // plain misses first
+                    if (f) {
+                        VIS |= lane_range(r, f);
+                        r += f;
+                        budget -= f;
+                    }
+                    if (f == run) break;
+                    if ((stop >> r) & 1ull) break;               // DUP lane or long match: single-step path
+                    // a resolved hit of 4..11 bytes at lane r
+                    const uint32_t len = 4u + (uint32_t)__builtin_amdgcn_readlane((int)st.extv, (int)r);
+                    VIS |= 1ull << r;
+                    H |= 1ull << r;
+                    first_hit = first_hit < r ? first_hit : r;
+                    const uint32_t nxt = r + len;
+                    COV |= lane_range(r, nxt <= kWave ? len : kWave - r);
+                    last_end = nxt;
+                    r = nxt;
+                    budget = 33;
+                    if (win.base + nxt >= limit) {               // :388-389
+                        done = true;
+                        break;
+                    }
+                    if (nxt <= kWave) INS |= 1ull << (nxt - 1);  // :391-392
+                    else insert_pending = true;
+                    if (nxt >= kWave) break;                     // the copy ran out of the window
+                }
+                ip = win.base + r;
+                skip = 64u - budget;
+
+                // ---- table: every probed lane and every "ip - 1" lane inserts its own position ----
+                const unsigned long long C = VIS | INS;
+                State::commit(table, win, C & ~st.dup, lane);
+                for (unsigned long long d = C & st.dup; d; d &= d - 1)      // shared slots: in position order
+                    State::commit(table, win, d & (~d + 1), lane);
+
+                if (H) {
+                    // ---- emission ----
+                    const uint32_t p0 = win.base + first_hit;
+                    if (p0 > next_emit)                          // the run in front of the first copy may start in an earlier window
+                        op = emit_literal_windowed(dst, op, blk, next_emit, p0 - next_emit, win.base, win.x0, lane);
+                    const uint32_t end_lane = last_end < kWave ? last_end : kWave;
+                    const unsigned long long LIT = lane_range(first_hit, end_lane - first_hit) & ~COV;
+                    const unsigned long long LS = LIT & ~(LIT << 1);            // first lane of each literal run
+                    const uint32_t off = win.base + lane - (st.ent & 0xffffu);  // meaningful in H lanes
+                    const uint32_t len = 4u + st.extv;
+                    const bool is_hit = __builtin_amdgcn_inverse_ballot_w64(H);
+                    const unsigned long long H3 = __ballot(is_hit && off >= 2048u);
+                    uint32_t P = mbcnt64(LIT, op);
+                    P = mbcnt64(H, P);
+                    P = mbcnt64(H, P);
+                    P = mbcnt64(H3, P);
+                    P = mbcnt64(LS, P);
+                    const bool is_ls = __builtin_amdgcn_inverse_ballot_w64(LS);
+                    if (__builtin_amdgcn_inverse_ballot_w64(LIT)) dst[P + (is_ls ? 1u : 0u)] = (uint8_t)win.x0;
+                    if (is_ls) {
+                        const uint32_t runlen = (uint32_t)__builtin_ctzll(~LIT >> lane);   // a copy follows every run
+                        dst[P] = (uint8_t)((runlen - 1) << 2);                          // :202-207, runs here are <= 59
+                    }
+                    if (is_hit) {
+                        uint32_t b01;
+                        if (off < 2048u) b01 = (1u + ((len - 4u) << 2) + ((off >> 8) << 5)) | ((off & 0xffu) << 8);   // :234-239
+                        else b01 = (2u + ((len - 1u) << 2)) | ((off & 0xffu) << 8);                                    // :240-245
+                        dst[P] = (uint8_t)b01;
+                        dst[P + 1] = (uint8_t)(b01 >> 8);
+                        if (off >= 2048u) dst[P + 2] = (uint8_t)(off >> 8);
+                    }
+                    op += (uint32_t)__builtin_popcountll(LIT) + 2u * (uint32_t)__builtin_popcountll(H) +
+                          (uint32_t)__builtin_popcountll(H3) + (uint32_t)__builtin_popcountll(LS);
+                    next_emit = win.base + last_end;
+                }
+                if (done) break;
+                if (insert_pending) {                            // :391-392 for a copy that ended in a later window
+                    if (win.ensure(ip - 1, lane)) st.invalidate();
+                    State::commit(table, win, 1ull << (ip - 1 - win.base), lane);
+                }
+                continue;
+            }
+
+            // ---------------- single step: DUP lane, long match, or stride > 1 ----------------
+            uint32_t cand = 0, ext = 0;
+            bool hit;
+            if (!((st.dup >> r) & 1ull)) {
+                State::commit(table, win, 1ull << r, lane);
+                hit = (st.hit >> r) & 1ull;
+                if (hit) {
+                    cand = (uint32_t)__builtin_amdgcn_readlane((int)st.ent, (int)r) & 0xffffu;
+                    ext = (uint32_t)__builtin_amdgcn_readlane((int)st.extv, (int)r);
+                }
+            } else {
+                // this lane shares its table slot with another lane of the window: ask the table itself
+                const uint32_t cur = win.bytes_at(ip);
+                const uint32_t mine = win.entry_at(ip);
+                const uint32_t old = table.exchange(win.hash_at(ip), mine, lane);
+                cand = old & 0xffffu;
+                hit = false;
+                if (!Table::certain_miss(old, mine)) {
+                    CandidateBytes cb;
+                    cb.fetch(base16, start + cand);
+                    if (cur == cb.c0) {
+                        ext = ext_from_candidate(win, ip, cb);
+                        hit = true;
+                    }
+                }
+            }
+            if (!hit) {
+                ip += step;
+                ++skip;
+                continue;
+            }
+            if (ip > next_emit) op = emit_literal_windowed(dst, op, blk, next_emit, ip - next_emit, win.base, win.x0, lane);   // :355
+            const uint32_t mbase = ip;
+            uint32_t matched = 4 + ext;                          // find_match_length (:176-193)
+            if (ext == 8) matched = 12 + match_extend(blk, cand + 12, ip + 12, n, lane);
+            ip += matched;
+            op = emit_copy_packed(dst, op, mbase - cand, matched, lane);
+            next_emit = ip;
+            if (ip >= limit) break;                              // :388-389
+            if (win.ensure(ip - 1, lane)) st.invalidate();
+            State::commit(table, win, 1ull << (ip - 1 - win.base), lane);   // :391-392
+            skip = 31;
+        }
+    }
+
+    // emit_remainder (:405-410) and the size prefix (:412)
+    if (next_emit < n) op = emit_literal(dst, op, blk + next_emit, n - next_emit, lane);
+    if (lane == 0) {
+        st32(dst, op - 4);
+        *block_bytes_out = op;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // next_block == nullptr: static grid-stride assignment; otherwise blocks are drawn from the shared atomic counter,
 // which lets this kernel run CONCURRENTLY with compress_blocks_global_table_kernel on the same container (the
 // LDS-table waves fill 5 wave slots per CU with low-latency tables, the global-table waves the other 27).
+template <uint32_t kAhead, int kForm = 0>
 __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
                                                                        uint32_t block_size, uint8_t* __restrict__ slots,
                                                                        uint32_t slot_stride,
@@ -493,6 +1074,7 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uin
                                                                        uint32_t* next_block)
 {
     __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTableEntries];
+    __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kForm ? kDupSlots : 16];
     const uint32_t lane = threadIdx.x;
     uint32_t b = blockIdx.x;
     for (;;) {
@@ -507,14 +1089,22 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uin
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
         const uint8_t* __restrict__ blk = in + start;
         (void)blk;
-        compress_one_block_windowed(in, start, in_len, n, slots + (uint64_t)b * slot_stride, LdsTable{table}, lane,
-                                    block_bytes + b);
+        if (kForm == 2)
+            compress_one_block_bulk<LdsTable, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, LdsTable{table},
+                                                      lane, block_bytes + b, (lds_bytes_t)dup_scratch);
+        else if (kForm == 1)
+            compress_one_block_masked<LdsTable, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, LdsTable{table},
+                                                        lane, block_bytes + b, (lds_bytes_t)dup_scratch);
+        else
+            compress_one_block_windowed<LdsTable, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride,
+                                                          LdsTable{table}, lane, block_bytes + b);
         if (next_block && lane == 0) atomicAdd(next_block + 4, 1u);   // statistics: blocks taken by the LDS-table form
         __syncthreads();
         b += gridDim.x;
     }
 }
 
+template <uint32_t kAhead, int kForm = 0>
 __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
                                                                           uint32_t block_size, uint8_t* __restrict__ slots,
                                                                           uint32_t slot_stride,
@@ -522,6 +1112,7 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
                                                                           uint32_t num_blocks, uint32_t* table_scratch,
                                                                           uint32_t* next_block)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kForm ? kDupSlots : 16];
     const uint32_t lane = threadIdx.x;
     const TaggedGlobalTable table{table_scratch + (size_t)blockIdx.x * kMaxTableEntries};
     for (;;) {
@@ -532,7 +1123,15 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
         const uint64_t start = (uint64_t)b * block_size;
         const uint64_t left = in_len - start;
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
-        compress_one_block_windowed(in, start, in_len, n, slots + (uint64_t)b * slot_stride, table, lane, block_bytes + b);
+        if (kForm == 2)
+            compress_one_block_bulk<TaggedGlobalTable, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, table,
+                                                               lane, block_bytes + b, (lds_bytes_t)dup_scratch);
+        else if (kForm == 1)
+            compress_one_block_masked<TaggedGlobalTable, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, table,
+                                                                 lane, block_bytes + b, (lds_bytes_t)dup_scratch);
+        else
+            compress_one_block_windowed<TaggedGlobalTable, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride,
+                                                                   table, lane, block_bytes + b);
     }
 }
 

@@ -10,6 +10,10 @@
 
 #include "snappy_kernels.hpp"
 
+#ifndef EMU_K1_AHEAD
+#define EMU_K1_AHEAD 64
+#endif
+
 namespace emu {
 
 constexpr int kStack = 256 * 1024;
@@ -182,8 +186,25 @@ void launch(uint32_t grid, uint32_t block, const std::function<void()>& body)
 extern "C" {
 
 // Runs compress_blocks_kernel + scan + gather on the CPU emulator.  Returns stream length.
+// variant = kernel form (1 LDS table, 3 global table, 4 lane-per-block, 5 group) + 100 * look-ahead code
+// (0 = EMU_K1_AHEAD, 1 = off, 2 = 4, 3 = 8, 4 = 16, 5 = 64) + 1000 for the masked form, + 2000 for the bulk form (chunk = look-ahead, needs > 0)
+#define EMU_AHEAD_DISPATCH(code, CALL)                         \
+    switch (code) {                                            \
+    case 1: { constexpr uint32_t kA = 0; CALL; } break;        \
+    case 2: { constexpr uint32_t kA = 4; CALL; } break;        \
+    case 3: { constexpr uint32_t kA = 8; CALL; } break;        \
+    case 4: { constexpr uint32_t kA = 16; CALL; } break;       \
+    case 5: { constexpr uint32_t kA = 64; CALL; } break;       \
+    default: { constexpr uint32_t kA = EMU_K1_AHEAD; CALL; }   \
+    }
+
 uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_t* stream, uint64_t stream_cap, int variant)
 {
+    const int form = variant / 1000;
+    const bool masked = form != 0;
+    variant %= 1000;
+    const int ahead_code = variant / 100;
+    variant %= 100;
     const uint64_t need = 4ull + 32ull + block_size + block_size / 6;
     const uint32_t stride = (uint32_t)((need + 15) & ~15ull);
     const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
@@ -202,8 +223,16 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
         std::vector<uint32_t> tables((size_t)grid * 16384, 0xBEEFBEEFu);
         uint32_t counter = 0;
         emu::launch(grid, 64, [&] {
-            snappy_hip::compress_blocks_global_table_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb,
-                                                            tables.data(), &counter);
+            if (form == 2) {
+                EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 2>(
+                                                   inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter)));
+            } else if (masked) {
+                EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 1>(
+                                                   inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter)));
+            } else {
+                EMU_AHEAD_DISPATCH(ahead_code, snappy_hip::compress_blocks_global_table_kernel<kA>(
+                                                   inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter));
+            }
         });
     } else if (nb && variant == 5) {
         const uint32_t grid = nb < 8 ? 1 : 2;
@@ -219,8 +248,16 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
                 if (emu::bidx().x * 64 < nb)
                     snappy_hip::compress_blocks_lane_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, lane_tables.data(), 1);
             } else
-                snappy_hip::compress_blocks_lds_table_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb,
-                                                             nullptr);
+                if (form == 2) {
+                    EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_lds_table_kernel<(kA ? kA : 8), 2>(
+                                                       inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, nullptr)));
+                } else if (masked) {
+                    EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_lds_table_kernel<(kA ? kA : 8), 1>(
+                                                       inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, nullptr)));
+                } else {
+                    EMU_AHEAD_DISPATCH(ahead_code, snappy_hip::compress_blocks_lds_table_kernel<kA>(
+                                                       inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, nullptr));
+                }
         });
     emu::launch(1, 1024, [&] {
         snappy_hip::scan_block_bytes_kernel(bytes.data(), nb, (uint32_t)n, block_size, stream, offsets.data(), &stream_len);

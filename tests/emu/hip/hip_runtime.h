@@ -51,6 +51,22 @@ void syncthreads(int site);
 #define __shfl(v, l) ((int)emu::collective(emu::OP_READLANE, (uint64_t)(uint32_t)(v), (uint32_t)(l), __LINE__))
 #define __shfl_up(v, d) ((int)emu::collective(emu::OP_SHFL_UP, (uint64_t)(uint32_t)(v), (uint32_t)(d), __LINE__))
 #define __syncthreads() emu::syncthreads(__LINE__)
+#define SNAPPY_EMU 1
+// popcount of the mask bits below this lane (v_mbcnt_lo_u32_b32 / v_mbcnt_hi_u32_b32)
+static inline uint32_t emu_mbcnt_lo(uint32_t mask, uint32_t base, uint32_t lane)
+{
+    const uint32_t below = lane >= 32 ? 0xffffffffu : ((1u << lane) - 1u);
+    return base + (uint32_t)__builtin_popcount(mask & below);
+}
+static inline uint32_t emu_mbcnt_hi(uint32_t mask, uint32_t base, uint32_t lane)
+{
+    const uint32_t below = lane <= 32 ? 0u : ((1u << (lane - 32)) - 1u);
+    return base + (uint32_t)__builtin_popcount(mask & below);
+}
+#define __builtin_amdgcn_mbcnt_lo(m, b) emu_mbcnt_lo((uint32_t)(m), (uint32_t)(b), emu::tidx().x & 63u)
+#define __builtin_amdgcn_mbcnt_hi(m, b) emu_mbcnt_hi((uint32_t)(m), (uint32_t)(b), emu::tidx().x & 63u)
+// exec = mask: true in the lanes whose bit is set (no cross-lane traffic)
+#define __builtin_amdgcn_inverse_ballot_w64(m) ((((unsigned long long)(m)) >> (emu::tidx().x & 63u)) & 1ull)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 
 // single-threaded fibers: a plain read-modify-write is atomic
