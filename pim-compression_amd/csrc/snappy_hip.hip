@@ -100,6 +100,7 @@ constexpr int kDefaultDecompressVariant = 1;   // the concurrent LDS+global form
 constexpr int kDefaultK1Ahead = 64;     // look-ahead of the global-table form (64 = the whole cursor window)
 constexpr int kDefaultK1AheadLds = 64;  // look-ahead of the LDS-table form
 constexpr int kDefaultK1Form = 0;
+constexpr int kDefaultK1Filter = 0;
 constexpr int kDefaultK1FormLds = 0;
 constexpr int kDefaultLdsWaves = 1024;   // 4 LDS-table wavefronts per CU beside 28 global-table ones (measured best)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
@@ -180,6 +181,27 @@ void launch_k1_global(uint32_t grid, hipStream_t st, const uint8_t* d_in, uint64
     hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<kAhead, kForm>), dim3(grid), dim3(64), 0, st, d_in,
                        input_len, block_size, d_slots, slot_stride, d_block_bytes, nb, tables, counter);
 }
+// same, with the LDS "slot written" filter in front of the table (SNAPPY_HIP_K1_FILTER=1)
+template <uint32_t kAhead, int kForm>
+void launch_k1_global_filtered(uint32_t grid, hipStream_t st, const uint8_t* d_in, uint64_t input_len, uint32_t block_size,
+                               uint8_t* d_slots, uint32_t slot_stride, uint32_t* d_block_bytes, uint32_t nb, uint32_t* tables,
+                               uint32_t* counter)
+{
+    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<kAhead, kForm, true>), dim3(grid), dim3(64), 0, st, d_in,
+                       input_len, block_size, d_slots, slot_stride, d_block_bytes, nb, tables, counter);
+}
+#define SNAPPY_K1_DISPATCH_FILTERED(ahead, form, ...)                                   \
+    do {                                                                                \
+        if ((form) == 2) {                                                              \
+            if ((ahead) >= 64) launch_k1_global_filtered<64, 2>(__VA_ARGS__);           \
+            else launch_k1_global_filtered<32, 2>(__VA_ARGS__);                         \
+        } else if ((form) == 1) {                                                       \
+            launch_k1_global_filtered<64, 1>(__VA_ARGS__);                              \
+        } else {                                                                        \
+            if ((ahead) >= 64) launch_k1_global_filtered<64, 0>(__VA_ARGS__);           \
+            else launch_k1_global_filtered<16, 0>(__VA_ARGS__);                         \
+        }                                                                               \
+    } while (0)
 template <uint32_t kAhead, int kForm>
 void launch_k1_lds(uint32_t grid, uint32_t lds, hipStream_t st, const uint8_t* d_in, uint64_t input_len, uint32_t block_size,
                    uint8_t* d_slots, uint32_t slot_stride, uint32_t* d_block_bytes, uint32_t nb, uint32_t* counter)
@@ -191,12 +213,10 @@ void launch_k1_lds(uint32_t grid, uint32_t lds, hipStream_t st, const uint8_t* d
     do {                                                        \
         if ((form) == 2) {                                      \
             if ((ahead) >= 64) fn<64, 2>(__VA_ARGS__);          \
-            else if ((ahead) >= 32) fn<32, 2>(__VA_ARGS__);     \
-            else fn<16, 2>(__VA_ARGS__);                        \
+            else fn<32, 2>(__VA_ARGS__);                        \
         } else if ((form) == 1) {                               \
             if ((ahead) >= 64) fn<64, 1>(__VA_ARGS__);          \
-            else if ((ahead) >= 32) fn<32, 1>(__VA_ARGS__);     \
-            else fn<16, 1>(__VA_ARGS__);                        \
+            else fn<32, 1>(__VA_ARGS__);                        \
         } else {                                                \
             if ((ahead) >= 64) fn<64, 0>(__VA_ARGS__);          \
             else if ((ahead) >= 32) fn<32, 0>(__VA_ARGS__);     \
@@ -309,6 +329,7 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
     const int k1_ahead_lds = env_int("SNAPPY_HIP_K1_AHEAD_LDS", kDefaultK1AheadLds);
     const int k1_masked = env_int("SNAPPY_HIP_K1_FORM", kDefaultK1Form);          // 0 windowed, 1 masked, 2 bulk
     const int k1_masked_lds = env_int("SNAPPY_HIP_K1_FORM_LDS", kDefaultK1FormLds);
+    const bool k1_filter = env_int("SNAPPY_HIP_K1_FILTER", kDefaultK1Filter) != 0;
     const dim3 grid((uint32_t)nb), block(64);
     hipStream_t st = (hipStream_t)stream;
     if (variant == kVariantGroup) {
@@ -367,12 +388,20 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
             SNAPPY_K1_DISPATCH(launch_k1_lds, k1_ahead_lds, k1_masked_lds, lds_waves, 0u, helper, d_in, input_len, block_size, d_slots, slot_stride,
                                d_block_bytes, (uint32_t)nb, counter);
             HIP_TRY(hipEventRecord(ev_end, helper));
-            SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride, d_block_bytes,
-                               (uint32_t)nb, tables, counter);
+            if (k1_filter)
+                SNAPPY_K1_DISPATCH_FILTERED(k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride,
+                                            d_block_bytes, (uint32_t)nb, tables, counter);
+            else
+                SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride,
+                                   d_block_bytes, (uint32_t)nb, tables, counter);
             HIP_TRY(hipStreamWaitEvent(st, ev_end, 0));                // the caller's stream resumes when both are done
         } else {
-            SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride, d_block_bytes,
-                               (uint32_t)nb, tables, counter);
+            if (k1_filter)
+                SNAPPY_K1_DISPATCH_FILTERED(k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride,
+                                            d_block_bytes, (uint32_t)nb, tables, counter);
+            else
+                SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride,
+                                   d_block_bytes, (uint32_t)nb, tables, counter);
         }
     }
     HIP_TRY(hipGetLastError());

@@ -15,6 +15,7 @@
 // snappy/snappy_decompress.c:218-289 (cited per function below).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace snappy_hip {
@@ -278,6 +279,20 @@ struct CandidateBytes {
     __device__ __forceinline__ uint64_t next8() const { return (uint64_t)c1 | ((uint64_t)c2 << 32); }
 };
 
+// LDS pointers keep their address space (ds_* instead of flat_*); the CPU emulator sees plain pointers.
+#ifdef SNAPPY_EMU
+typedef volatile uint8_t* lds_bytes_t;
+typedef volatile uint32_t* lds_words_t;
+__device__ __forceinline__ void lds_or(lds_words_t p, uint32_t v) { *p = *p | v; }
+#else
+typedef volatile __attribute__((address_space(3))) uint8_t* lds_bytes_t;
+typedef volatile __attribute__((address_space(3))) uint32_t* lds_words_t;
+__device__ __forceinline__ void lds_or(lds_words_t p, uint32_t v)
+{
+    __hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+#endif
+
 // Tagged hash table of the windowed form: entry = tag << 16 | position (u32), where the tag is a 16-bit function
 // of the 4 bytes at that position.  The positions stored and returned are exactly the reference's
 // (snappy_compress.c:346-347, :392-397); the tag only lets a probe whose candidate has a DIFFERENT tag -- hence
@@ -315,6 +330,53 @@ struct TaggedGlobalTable {      // u32 entries in the global scratch: tag << 16 
     // per-lane (divergent index) accessors for the look-ahead gather
     __device__ __forceinline__ uint32_t load_lane(uint32_t h) const { return t[h]; }
     __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const { t[h] = entry; }
+    __device__ __forceinline__ TaggedGlobalTable with_empty(uint32_t) const { return *this; }
+};
+
+// TaggedGlobalTable behind a one-bit-per-slot "written in this block" filter in LDS (2 KiB per wavefront).  Early in a
+// block most slots still hold the initial entry (candidate position 0, :145 + :346), and the speculative gathers of the
+// look-ahead forms read 64 slots per 64 input bytes -- one random 64-byte HBM line per input byte, which is what bounds
+// those forms (~58 G random lines/s on MI355X).  With the filter a slot that was not written since the block started is
+// answered from a register (the initial entry), its line is never fetched, and the table needs no per-block
+// initialisation at all: whatever an earlier block left in the scratch is unreachable until this block overwrites it.
+struct FilteredGlobalTable {
+    uint32_t* __restrict__ t;
+    lds_words_t written;        // kMaxTableEntries / 32 words
+    uint32_t empty;             // tag(position 0) << 16 | 0
+    __device__ __forceinline__ void init(uint32_t entries, uint32_t, uint32_t lane) const
+    {
+        for (uint32_t i = lane; i < entries / 32; i += kWave) written[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ bool is_written(uint32_t h) const { return (written[h >> 5] >> (h & 31u)) & 1u; }
+    __device__ __forceinline__ uint32_t exchange(uint32_t h, uint32_t entry, uint32_t lane) const
+    {
+        uint32_t hv = h;
+        SNAPPY_PIN(hv);
+        uint32_t old = empty;
+        if (is_written(hv)) old = t[hv];
+        old = uni(old);
+        t[hv] = entry;
+        if (lane == 0) lds_or(written + (h >> 5), 1u << (h & 31u));
+        __builtin_amdgcn_wave_barrier();
+        return old;
+    }
+    __device__ __forceinline__ void put(uint32_t h, uint32_t entry, uint32_t lane) const
+    {
+        uint32_t hv = h;
+        SNAPPY_PIN(hv);
+        t[hv] = entry;
+        if (lane == 0) lds_or(written + (h >> 5), 1u << (h & 31u));
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ static bool certain_miss(uint32_t old, uint32_t entry) { return ((old ^ entry) >> 16) != 0; }
+    __device__ __forceinline__ uint32_t load_lane(uint32_t h) const { return is_written(h) ? t[h] : empty; }
+    __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const
+    {
+        t[h] = entry;
+        lds_or(written + (h >> 5), 1u << (h & 31u));
+    }
+    __device__ __forceinline__ FilteredGlobalTable with_empty(uint32_t e) const { return FilteredGlobalTable{t, written, e}; }
 };
 
 struct LdsTable {               // the reference's own layout: u16 positions, in LDS (no room for tags: 32 KiB per block)
@@ -339,6 +401,7 @@ struct LdsTable {               // the reference's own layout: u16 positions, in
     __device__ __forceinline__ static bool certain_miss(uint32_t, uint32_t) { return false; }
     __device__ __forceinline__ uint32_t load_lane(uint32_t h) const { return t[h]; }
     __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const { t[h] = (uint16_t)entry; }
+    __device__ __forceinline__ LdsTable with_empty(uint32_t) const { return *this; }
 };
 
 // Emitters of the windowed form.  Element headers are packed into one dword and stored by a single lane
@@ -465,18 +528,17 @@ __device__ __forceinline__ bool probe_cached(const Table& table, EntryCache<Tabl
 template <class Table, uint32_t kAhead = 0>
 __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __restrict__ base16, uint64_t start,
                                                             uint64_t in_len, uint32_t n, uint8_t* __restrict__ dst,
-                                                            const Table table, uint32_t lane,
+                                                            const Table table_in, uint32_t lane,
                                                             uint32_t* __restrict__ block_bytes_out)
 {
     const uint8_t* __restrict__ blk = base16 + start;
     // get_hash_table, snappy_compress.c:139-146 (+ shift, :288)
     const uint32_t ts = table_entries_for(n);
     const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
-    if (n >= kInputMargin) {
-        // "empty" = candidate position 0 (:346 on a zeroed table), carrying position 0's tag
-        const uint32_t e_zero = ((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u;
-        table.init(ts, e_zero, lane);
-    }
+    // "empty" = candidate position 0 (:346 on a zeroed table), carrying position 0's tag
+    const uint32_t e_zero = (n >= kInputMargin) ? (((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u) : 0u;
+    const Table table = table_in.with_empty(e_zero);
+    if (n >= kInputMargin) table.init(ts, e_zero, lane);
     __builtin_amdgcn_wave_barrier();
 
     uint32_t op = 4;          // :291
@@ -583,6 +645,13 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
     __builtin_amdgcn_wave_barrier();
 }
 
+// floor(x / d) for x < 64, 1 <= d < 64:  (x * kRecip16[d]) >> 16  with kRecip16[d] = 65536/d + 1
+__constant__ uint32_t kRecip16[64] = {
+        0, 65537, 32769, 21846, 16385, 13108, 10923,  9363,  8193,  7282,  6554,  5958,  5462,  5042,  4682,  4370,
+     4097,  3856,  3641,  3450,  3277,  3121,  2979,  2850,  2731,  2622,  2521,  2428,  2341,  2260,  2185,  2115,
+     2049,  1986,  1928,  1873,  1821,  1772,  1725,  1681,  1639,  1599,  1561,  1525,  1490,  1457,  1425,  1395,
+     1366,  1338,  1311,  1286,  1261,  1237,  1214,  1192,  1171,  1150,  1130,  1111,  1093,  1075,  1058,  1041};
+
 // ---------------------------------------------------------------------------
 // K1, masked form.  The PMC profile of the look-ahead form above shows it instruction-issue bound (SQ_WAIT_INST_ANY +
 // SQ_ACTIVE_INST_ANY > 50 % of wave cycles, ~80 instructions per probe).  This form keeps the same speculative gather but
@@ -600,12 +669,7 @@ __device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __res
 //    the order the reference made them in does not matter), and a resolved hit costs two v_readlane.
 // Decisions, table contents after every step, and output bytes are those of snappy_compress.c:284-413.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kDupSlots = 1024;   // bytes of LDS per wavefront for the duplicate-slot test
-#ifdef SNAPPY_EMU
-typedef volatile uint8_t* lds_bytes_t;
-#else
-typedef volatile __attribute__((address_space(3))) uint8_t* lds_bytes_t;   // keeps the accesses ds_*, not flat_*
-#endif
+constexpr uint32_t kDupSlots = 1024;   // bytes of LDS per wavefront for the duplicate-slot test (two tables of 512)
 
 __device__ __forceinline__ uint32_t ctz64_or(unsigned long long x, uint32_t if_zero)
 {
@@ -617,20 +681,28 @@ __device__ __forceinline__ unsigned long long lane_range(uint32_t lo, uint32_t c
     return (~0ull >> (64u - cnt)) << lo;
 }
 
-// Superset of the lanes whose table slot `h` is shared with another lane: lanes race for a byte per slot; every loser, and
-// every winner that a loser then marks, is reported.  (A slot group of one reads back its own lane id twice.)
+// Superset of the lanes whose table slot `h` is shared with another lane.  Two byte tables indexed by overlapping halves of the
+// hash (bits 0-8 and 5-13): lanes race for a byte per slot; every loser, and every winner that a loser then marks, "has
+// company" in that table.  Lanes with the same hash have company in both tables; two lanes with different hashes cannot
+// collide in both (bits 0-8 and 5-13 equal means all 14 equal), so what is reported beyond the true sharers is only the
+// rare lane that collides with one neighbour in the first table and with another in the second.
 __device__ __forceinline__ unsigned long long dup_slot_lanes(lds_bytes_t scratch, uint32_t h, uint32_t lane)
 {
-    const uint32_t slot = h & (kDupSlots - 1);
-    scratch[slot] = (uint8_t)lane;
+    const uint32_t sa = h & (kDupSlots / 2 - 1);
+    const uint32_t sb = kDupSlots / 2 + ((h >> 5) & (kDupSlots / 2 - 1));
+    scratch[sa] = (uint8_t)lane;
+    scratch[sb] = (uint8_t)lane;
     __builtin_amdgcn_wave_barrier();
-    const uint32_t winner = scratch[slot];
+    const uint32_t wa = scratch[sa];
+    const uint32_t wb = scratch[sb];
     __builtin_amdgcn_wave_barrier();
-    if (winner != lane) scratch[slot] = 0xff;
+    if (wa != lane) scratch[sa] = 0xff;              // lane ids are < 64
+    if (wb != lane) scratch[sb] = 0xff;
     __builtin_amdgcn_wave_barrier();
-    const uint32_t mark = scratch[slot];
+    const uint32_t ma = scratch[sa];
+    const uint32_t mb = scratch[sb];
     __builtin_amdgcn_wave_barrier();
-    return __ballot(mark == 0xff);
+    return __ballot(ma == 0xff && mb == 0xff);
 }
 
 template <class Table, uint32_t kChunk>
@@ -707,7 +779,7 @@ __device__ __forceinline__ uint32_t ext_from_candidate(const CursorWindow& win, 
 
 template <class Table, uint32_t kChunk>
 __device__ __forceinline__ void compress_one_block_masked(const uint8_t* __restrict__ base16, uint64_t start, uint64_t in_len,
-                                                          uint32_t n, uint8_t* __restrict__ dst, const Table table,
+                                                          uint32_t n, uint8_t* __restrict__ dst, const Table table_in,
                                                           uint32_t lane, uint32_t* __restrict__ block_bytes_out,
                                                           lds_bytes_t dup_scratch)
 {
@@ -715,10 +787,10 @@ __device__ __forceinline__ void compress_one_block_masked(const uint8_t* __restr
     const uint8_t* __restrict__ blk = base16 + start;
     const uint32_t ts = table_entries_for(n);                    // get_hash_table, :139-146 (+ shift, :288)
     const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
-    if (n >= kInputMargin) {
-        const uint32_t e_zero = ((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u;
-        table.init(ts, e_zero, lane);
-    }
+    // "empty" = candidate position 0 (:346 on a zeroed table), carrying position 0's tag
+    const uint32_t e_zero = (n >= kInputMargin) ? (((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u) : 0u;
+    const Table table = table_in.with_empty(e_zero);
+    if (n >= kInputMargin) table.init(ts, e_zero, lane);
     __builtin_amdgcn_wave_barrier();
 
     uint32_t op = 4;          // :291
@@ -875,20 +947,91 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t add)
 {
     return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, add));
 }
+// lanes [0, n), 1 <= n <= 64
+__device__ __forceinline__ unsigned long long lanes_below(uint32_t n) { return ~0ull >> (64u - n); }
+
+// The walk of one segment.  `inter` = HIT | stop lanes (stop = DUP, long matches, and every lane >= hi), `lenv` = per-lane
+// match length for HIT lanes (4..11), r < hi <= 64 the cursor lane, B the number of stride-1 probes still allowed (:339).
+// Per match: skip the misses (first set bit of inter), take the hit (H), cover its lanes (COV), continue behind it.
+// Returns why it stopped: 0 = behind a copy at a lane >= hi, 1 = no hit within the next B lanes (r NOT advanced),
+// 2 = r is a stop lane (not probed).  On gfx950 this is 16 instructions per match, hand-scheduled; the C++ body is
+// the same algorithm for the CPU emulator.
+__device__ __forceinline__ uint32_t segment_walk(unsigned long long inter, unsigned long long stopm, uint32_t lenv, uint32_t hi,
+                                                 uint32_t& r, uint32_t& B, unsigned long long& H, unsigned long long& COV)
+{
+    uint32_t why;
+#ifdef SNAPPY_EMU
+    for (;;) {
+        const unsigned long long m = inter >> r;
+        const uint32_t f = m ? (uint32_t)__builtin_ctzll(m) : 0xffffffffu;
+        if (f >= B) {
+            why = 1;
+            break;
+        }
+        r += f;
+        B -= f;
+        if ((stopm >> r) & 1ull) {
+            why = 2;
+            break;
+        }
+        H |= 1ull << r;
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)lenv, (int)r);
+        COV |= ((1ull << e) - 1ull) << r;
+        r += e;
+        B = 33;
+        if (r < hi) continue;
+        why = 0;
+        break;
+    }
+#else
+    unsigned long long m;
+    uint32_t f, e;
+    asm volatile(
+        "1:\n"
+        "  s_lshr_b64 %[m], %[inter], %[r]\n"
+        "  s_ff1_i32_b64 %[f], %[m]\n"          // -1 when no bit is set
+        "  s_cmp_ge_u32 %[f], %[B]\n"
+        "  s_cbranch_scc1 2f\n"
+        "  s_add_u32 %[r], %[r], %[f]\n"
+        "  s_sub_u32 %[B], %[B], %[f]\n"
+        "  s_bitcmp1_b64 %[stopm], %[r]\n"
+        "  s_cbranch_scc1 3f\n"
+        "  s_bitset1_b64 %[H], %[r]\n"
+        "  v_readlane_b32 %[e], %[lenv], %[r]\n"
+        "  s_bfm_b64 %[m], %[e], %[r]\n"        // ((1 << e) - 1) << r
+        "  s_or_b64 %[COV], %[COV], %[m]\n"
+        "  s_add_u32 %[r], %[r], %[e]\n"
+        "  s_movk_i32 %[B], 33\n"
+        "  s_cmp_lt_u32 %[r], %[hi]\n"
+        "  s_cbranch_scc1 1b\n"
+        "  s_mov_b32 %[why], 0\n"
+        "  s_branch 4f\n"
+        "2:\n"
+        "  s_mov_b32 %[why], 1\n"
+        "  s_branch 4f\n"
+        "3:\n"
+        "  s_mov_b32 %[why], 2\n"
+        "4:\n"
+        : [r] "+s"(r), [B] "+s"(B), [H] "+s"(H), [COV] "+s"(COV), [m] "=&s"(m), [f] "=&s"(f), [e] "=&s"(e), [why] "=&s"(why)
+        : [inter] "s"(inter), [stopm] "s"(stopm), [lenv] "v"(lenv), [hi] "s"(hi)
+        : "scc");
+#endif
+    return why;
+}
 
 template <class Table, uint32_t kChunk>
 __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restrict__ base16, uint64_t start, uint64_t in_len,
-                                                        uint32_t n, uint8_t* __restrict__ dst, const Table table, uint32_t lane,
+                                                        uint32_t n, uint8_t* __restrict__ dst, const Table table_in, uint32_t lane,
                                                         uint32_t* __restrict__ block_bytes_out, lds_bytes_t dup_scratch)
 {
     using State = MaskedWindowState<Table, kChunk>;
     const uint8_t* __restrict__ blk = base16 + start;
     const uint32_t ts = table_entries_for(n);                    // get_hash_table, :139-146 (+ shift, :288)
     const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
-    if (n >= kInputMargin) {
-        const uint32_t e_zero = ((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u;
-        table.init(ts, e_zero, lane);
-    }
+    // "empty" = candidate position 0 (:346 on a zeroed table), carrying position 0's tag
+    const uint32_t e_zero = (n >= kInputMargin) ? (((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u) : 0u;
+    const Table table = table_in.with_empty(e_zero);
+    if (n >= kInputMargin) table.init(ts, e_zero, lane);
     __builtin_amdgcn_wave_barrier();
 
     uint32_t op = 4;          // :291
@@ -913,96 +1056,111 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
             if (ip + step > limit) break;                        // :342-343 / :388-389
             if (win.ensure(ip, lane)) st.invalidate();
             uint32_t r = ip - win.base;
-            if (r >= uni(st.cov_end)) st.gather(table, win, dup_scratch, r, stride <= 1 ? kChunk : 1u, lane);
-            const unsigned long long stop = st.dup | st.longm;
+            if (r >= uni(st.cov_end)) st.gather(table, win, dup_scratch, r, kChunk, lane);
+            unsigned long long stopm = st.dup | st.longm;
 
-            if (stride <= 1 && !((stop >> r) & 1ull)) {
-                // ---------------- segment walk ----------------
+            if (!((stopm >> r) & 1ull)) {
+                // ---------------- segment ----------------
                 uint32_t hi = uni(st.cov_end);
                 const uint32_t lim = limit - win.base;           // lanes below may be probed (position + 1 <= limit)
                 hi = lim < hi ? lim : hi;
-                const unsigned long long interesting = st.hit | stop;
-                unsigned long long H = 0, VIS = 0, INS = 0, COV = 0;
-                uint32_t first_hit = 64, last_end = 0;
-                uint32_t budget = 64u - skip;                    // stride-1 probes left before :339 widens the stride
-                bool done = false, insert_pending = false;
-                for (;;) {
-                    uint32_t run = (r + budget < hi ? r + budget : hi);
-                    if (run <= r) break;                         // coverage, limit or stride-1 budget used up
-                    run -= r;
-                    const uint32_t f0 = ctz64_or(interesting >> r, 64u);
-                    const uint32_t f = f0 < run ? f0 : run;      // plain misses first
-                    if (f) {
-                        VIS |= lane_range(r, f);
-                        r += f;
-                        budget -= f;
+                if (hi < kWave) stopm |= ~0ull << hi;
+                const unsigned long long inter = st.hit | stopm;
+                unsigned long long pre = 0;                      // lanes probed by the strided prefix
+                uint32_t B = 64u - skip;                         // stride-1 probes left before :339 widens the stride
+                if (stride > 1) {
+                    // The scan is at stride s (:339): lanes r, r+s, ... are probed until one hits, the stride level is used
+                    // up (32 probes per level), or the window / limit ends.  Find the first interesting one with a mask.
+                    const uint32_t x = lane - r;
+                    bool mine = lane == r;
+                    if (stride < kWave) {
+                        const uint32_t q = (x * kRecip16[stride]) >> 16;     // x / stride for x < 64
+                        mine = lane >= r && x == q * stride;
                     }
-                    if (f == run) break;
-                    if ((stop >> r) & 1ull) break;               // DUP lane or long match: single-step path
-                    // a resolved hit of 4..11 bytes at lane r
-                    const uint32_t len = 4u + (uint32_t)__builtin_amdgcn_readlane((int)st.extv, (int)r);
-                    VIS |= 1ull << r;
-                    H |= 1ull << r;
-                    first_hit = first_hit < r ? first_hit : r;
-                    const uint32_t nxt = r + len;
-                    COV |= lane_range(r, nxt <= kWave ? len : kWave - r);
-                    last_end = nxt;
-                    r = nxt;
-                    budget = 33;
-                    if (win.base + nxt >= limit) {               // :388-389
-                        done = true;
-                        break;
+                    const uint32_t nrem = 32u - (skip & 31u);
+                    uint32_t hs = r + nrem * stride;
+                    hs = hs < hi ? hs : hi;
+                    const uint32_t lims = lim - (stride - 1u);               // position + stride <= limit
+                    hs = hs < lims ? hs : lims;                              // > r by the check at the top of the loop
+                    const unsigned long long smask = __ballot(mine) & lanes_below(hs);
+                    const unsigned long long m = inter & smask;
+                    const uint32_t p = ctz64_or(m, kWave);
+                    pre = p < kWave ? (p ? smask & lanes_below(p) : 0ull) : smask;
+                    const uint32_t cnt = (uint32_t)__builtin_popcountll(pre);
+                    skip += cnt;
+                    if (p == kWave || ((stopm >> p) & 1ull)) {               // no hit at this stride level here
+                        State::commit(table, win, pre, lane);                // (no DUP lane among them: those are stops)
+                        ip += cnt * stride;
+                        continue;
                     }
-                    if (nxt <= kWave) INS |= 1ull << (nxt - 1);  // :391-392
-                    else insert_pending = true;
-                    if (nxt >= kWave) break;                     // the copy ran out of the window
+                    r = p;
+                    B = 1;                                                   // the walk takes the hit at p right away
+                }
+                const uint32_t r0 = r;
+                unsigned long long H = 0, COV = 0;
+                const uint32_t why = segment_walk(inter, stopm, 4u + st.extv, hi, r, B, H, COV);
+                if (why == 1) {                                  // B (or all remaining) lanes of misses
+                    const uint32_t room = hi - r;
+                    const uint32_t adv = B < room ? B : room;
+                    r += adv;
+                    B -= adv;
                 }
                 ip = win.base + r;
-                skip = 64u - budget;
+                skip = 64u - B;
+                const bool done = (why == 0) && ip >= limit;     // :388-389 behind the last copy
+                const uint32_t r_end = r < kWave ? r : kWave;
 
-                // ---- table: every probed lane and every "ip - 1" lane inserts its own position ----
-                const unsigned long long C = VIS | INS;
+                // ---- table: every probed lane (:346-347, :397) and every "ip - 1" lane (:391-392) inserts its position ----
+                const unsigned long long interior = COV & ~H;
+                unsigned long long C = pre | (((~0ull << r0) & lanes_below(r_end)) & ~interior);   // probed lanes
+                unsigned long long endl = COV & ~(interior >> 1);                              // last lane of each copy
+                if (why == 0 && (r > kWave || done)) endl &= ~(1ull << (r_end - 1));           // the last copy's is not (yet) due
+                C |= endl;
                 State::commit(table, win, C & ~st.dup, lane);
-                for (unsigned long long d = C & st.dup; d; d &= d - 1)      // shared slots: in position order
+                for (unsigned long long d = C & st.dup; d; d &= d - 1)                         // shared slots: in position order
                     State::commit(table, win, d & (~d + 1), lane);
 
                 if (H) {
                     // ---- emission ----
+                    const uint32_t first_hit = (uint32_t)__builtin_ctzll(H);
+                    const uint32_t last_end = (why == 0) ? r_end : 64u - (uint32_t)__builtin_clzll(COV);
+                    uint32_t s0 = first_hit;
                     const uint32_t p0 = win.base + first_hit;
-                    if (p0 > next_emit)                          // the run in front of the first copy may start in an earlier window
+                    if (next_emit >= win.base && p0 - next_emit <= 60u) {
+                        s0 = next_emit - win.base;               // the first run is inside the window too
+                    } else if (p0 > next_emit) {                 // it started in an earlier window (or is 61+ bytes)
                         op = emit_literal_windowed(dst, op, blk, next_emit, p0 - next_emit, win.base, win.x0, lane);
-                    const uint32_t end_lane = last_end < kWave ? last_end : kWave;
-                    const unsigned long long LIT = lane_range(first_hit, end_lane - first_hit) & ~COV;
+                    }
+                    const unsigned long long LIT = ((~0ull << s0) & lanes_below(last_end)) & ~COV;
                     const unsigned long long LS = LIT & ~(LIT << 1);            // first lane of each literal run
                     const uint32_t off = win.base + lane - (st.ent & 0xffffu);  // meaningful in H lanes
                     const uint32_t len = 4u + st.extv;
                     const bool is_hit = __builtin_amdgcn_inverse_ballot_w64(H);
                     const unsigned long long H3 = __ballot(is_hit && off >= 2048u);
-                    uint32_t P = mbcnt64(LIT, op);
-                    P = mbcnt64(H, P);
-                    P = mbcnt64(H, P);
+                    uint32_t P = mbcnt64(H, 0);
+                    P = mbcnt64(LIT, op + 2u * P);
                     P = mbcnt64(H3, P);
                     P = mbcnt64(LS, P);
                     const bool is_ls = __builtin_amdgcn_inverse_ballot_w64(LS);
                     if (__builtin_amdgcn_inverse_ballot_w64(LIT)) dst[P + (is_ls ? 1u : 0u)] = (uint8_t)win.x0;
                     if (is_ls) {
                         const uint32_t runlen = (uint32_t)__builtin_ctzll(~LIT >> lane);   // a copy follows every run
-                        dst[P] = (uint8_t)((runlen - 1) << 2);                          // :202-207, runs here are <= 59
+                        dst[P] = (uint8_t)((runlen - 1) << 2);                          // :202-207, runs here are <= 60
                     }
                     if (is_hit) {
-                        uint32_t b01;
-                        if (off < 2048u) b01 = (1u + ((len - 4u) << 2) + ((off >> 8) << 5)) | ((off & 0xffu) << 8);   // :234-239
-                        else b01 = (2u + ((len - 1u) << 2)) | ((off & 0xffu) << 8);                                    // :240-245
-                        dst[P] = (uint8_t)b01;
-                        dst[P + 1] = (uint8_t)(b01 >> 8);
+                        uint32_t b0;
+                        if (off < 2048u) b0 = 1u + ((len - 4u) << 2) + ((off >> 8) << 5);   // :234-239
+                        else b0 = 2u + ((len - 1u) << 2);                                   // :240-245
+                        dst[P] = (uint8_t)b0;
+                        dst[P + 1] = (uint8_t)off;
                         if (off >= 2048u) dst[P + 2] = (uint8_t)(off >> 8);
                     }
                     op += (uint32_t)__builtin_popcountll(LIT) + 2u * (uint32_t)__builtin_popcountll(H) +
                           (uint32_t)__builtin_popcountll(H3) + (uint32_t)__builtin_popcountll(LS);
-                    next_emit = win.base + last_end;
+                    next_emit = win.base + ((why == 0) ? r : last_end);
                 }
                 if (done) break;
-                if (insert_pending) {                            // :391-392 for a copy that ended in a later window
+                if (why == 0 && r > kWave) {                     // :391-392 for a copy that ended in a later window
                     if (win.ensure(ip - 1, lane)) st.invalidate();
                     State::commit(table, win, 1ull << (ip - 1 - win.base), lane);
                 }
@@ -1104,7 +1262,7 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uin
     }
 }
 
-template <uint32_t kAhead, int kForm = 0>
+template <uint32_t kAhead, int kForm = 0, bool kFilter = false>
 __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
                                                                           uint32_t block_size, uint8_t* __restrict__ slots,
                                                                           uint32_t slot_stride,
@@ -1113,8 +1271,15 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
                                                                           uint32_t* next_block)
 {
     __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kForm ? kDupSlots : 16];
+    __shared__ __attribute__((aligned(16))) uint32_t slot_written[kFilter ? kMaxTableEntries / 32 : 4];
     const uint32_t lane = threadIdx.x;
-    const TaggedGlobalTable table{table_scratch + (size_t)blockIdx.x * kMaxTableEntries};
+    using Table = typename std::conditional<kFilter, FilteredGlobalTable, TaggedGlobalTable>::type;
+    Table table;
+    table.t = table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
+    if constexpr (kFilter) {
+        table.written = (lds_words_t)slot_written;
+        table.empty = 0;
+    }
     for (;;) {
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(next_block, 1u);
@@ -1124,13 +1289,13 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
         const uint64_t left = in_len - start;
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
         if (kForm == 2)
-            compress_one_block_bulk<TaggedGlobalTable, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, table,
+            compress_one_block_bulk<Table, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, table,
                                                                lane, block_bytes + b, (lds_bytes_t)dup_scratch);
         else if (kForm == 1)
-            compress_one_block_masked<TaggedGlobalTable, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, table,
+            compress_one_block_masked<Table, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, table,
                                                                  lane, block_bytes + b, (lds_bytes_t)dup_scratch);
         else
-            compress_one_block_windowed<TaggedGlobalTable, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride,
+            compress_one_block_windowed<Table, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride,
                                                                    table, lane, block_bytes + b);
     }
 }
@@ -1653,12 +1818,6 @@ __global__ __launch_bounds__(64) void index_streams_kernel(const StreamDesc* __r
 // Semantics: snappy_decompress.c:232-285 on well-formed streams, strict otherwise (per-block status).
 // ---------------------------------------------------------------------------
 
-// floor(x / d) for x < 64, 1 <= d < 64:  (x * kRecip16[d]) >> 16  with kRecip16[d] = 65536/d + 1
-__constant__ uint32_t kRecip16[64] = {
-        0, 65537, 32769, 21846, 16385, 13108, 10923,  9363,  8193,  7282,  6554,  5958,  5462,  5042,  4682,  4370,
-     4097,  3856,  3641,  3450,  3277,  3121,  2979,  2850,  2731,  2622,  2521,  2428,  2341,  2260,  2185,  2115,
-     2049,  1986,  1928,  1873,  1821,  1772,  1725,  1681,  1639,  1599,  1561,  1525,  1490,  1457,  1425,  1395,
-     1366,  1338,  1311,  1286,  1261,  1237,  1214,  1192,  1171,  1150,  1130,  1111,  1093,  1075,  1058,  1041};
 
 // Window loads: lane value = the 8 bytes at src[pos..pos+8), zero-filled at and beyond `avail`.
 // Split in two so that a prefetch can stay in flight: window_issue() only issues the (clamped-address)

@@ -224,6 +224,10 @@ def test_seeded_fuzz_vs_oracle(shb):
                                   "SNAPPY_HIP_K1_AHEAD_LDS": "64", "SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11",
                                   "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"},
                                  {"SNAPPY_HIP_K1_FORM_LDS": "2", "SNAPPY_HIP_K1_AHEAD_LDS": "32", "SNAPPY_HIP_COMPRESS_VARIANT": "1"},
+                                 {"SNAPPY_HIP_K1_FILTER": "1"}, {"SNAPPY_HIP_K1_FILTER": "1", "SNAPPY_HIP_K1_FORM": "1"},
+                                 {"SNAPPY_HIP_K1_FILTER": "1", "SNAPPY_HIP_K1_FORM": "2", "SNAPPY_HIP_LDS_WAVES": "0"},
+                                 {"SNAPPY_HIP_K1_FILTER": "1", "SNAPPY_HIP_K1_FORM": "2", "SNAPPY_HIP_K1_AHEAD": "32",
+                                  "SNAPPY_HIP_LDS_WAVES": "3", "SNAPPY_HIP_GT_WAVES": "9", "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"},
                                  {"SNAPPY_HIP_K1_AHEAD": "4", "SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11",
                                   "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"},
                                  {"SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11", "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"},
