@@ -712,6 +712,8 @@ struct MaskedWindowState {
     unsigned long long hit = 0;     // wave-uniform: lanes whose probe would hit
     unsigned long long dup = 0;     // wave-uniform: lanes that must not use the cache
     unsigned long long longm = 0;   // wave-uniform: HIT lanes with extv == 8
+    unsigned long long inserted = 0;// wave-uniform: window lanes whose position has been inserted (bulk form)
+    uint32_t xa = 0, xb = 0;        // per lane: le32 at position + 4 / + 8
     uint32_t cov_end = 0;           // lanes in [gather start, cov_end) are resolved
     bool dup_valid = false;
 
@@ -720,6 +722,7 @@ struct MaskedWindowState {
         cov_end = 0;
         hit = 0;
         dup_valid = false;
+        inserted = 0;
     }
 
     // le32(block + window base + lane + d), d in {4, 8}: from the current or the prefetched granule
@@ -731,6 +734,8 @@ struct MaskedWindowState {
         return (lane + d < kWave) ? a : b;
     }
 
+    // kWithDup: also read the slots of DUP lanes (their values hold only while no same-hash lane of the window is inserted)
+    template <bool kWithDup = false>
     __device__ __forceinline__ void gather(const Table& table, const CursorWindow& win, lds_bytes_t scratch, uint32_t r,
                                            uint32_t span, uint32_t lane)
     {
@@ -739,7 +744,7 @@ struct MaskedWindowState {
             dup_valid = true;
         }
         const uint32_t e = (r + span < kWave) ? r + span : kWave;
-        const unsigned long long gm = lane_range(r, e - r) & ~dup;
+        const unsigned long long gm = kWithDup ? lane_range(r, e - r) : (lane_range(r, e - r) & ~dup);
         const bool g = __builtin_amdgcn_inverse_ballot_w64(gm);
         if (g) ent = table.load_lane(win.h0);
         const uint32_t mine_l = win.e0 | (win.base + lane);
@@ -751,8 +756,8 @@ struct MaskedWindowState {
             k1 = ld32(c + 4);
             k2 = ld32(c + 8);
         }
-        const uint32_t xa = bytes_ahead(win, lane, 4);
-        const uint32_t xb = bytes_ahead(win, lane, 8);
+        xa = bytes_ahead(win, lane, 4);
+        xb = bytes_ahead(win, lane, 8);
         const uint32_t d0 = k1 ^ xa, d1 = k2 ^ xb;
         extv = d0 ? ((uint32_t)__builtin_ctz(d0) >> 3) : (d1 ? 4u + ((uint32_t)__builtin_ctz(d1) >> 3) : 8u);
         const bool hitl = worth && k0 == win.x0;
@@ -940,8 +945,8 @@ __device__ __forceinline__ void compress_one_block_masked(const uint8_t* __restr
 //   * emission (:355, :202-245): each lane derives its own output offset from the segment's masks with v_mbcnt --
 //       P(l) = op + #literal bytes + 2 * #copies + #3-byte copies + #literal headers   (all counted below lane l)
 //     literal lanes store their byte, run-start lanes the literal header, hit lanes the 2- or 3-byte copy element.
-// Anything else (DUP lanes, matches of 12+ bytes, strides > 1, window edges) ends the segment and takes the masked form's
-// single-step path.  Same decisions, same table contents at every read, same bytes as snappy_compress.c:284-413.
+// Anything else (DUP lanes, matches of 12+ bytes, window edges) ends the segment and takes a single step; a DUP lane is
+// resolved there from the window registers (the latest inserted lane with the same hash IS the table slot's content).  Same decisions, same table contents at every read, same bytes as snappy_compress.c:284-413.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t add)
 {
@@ -1056,7 +1061,7 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
             if (ip + step > limit) break;                        // :342-343 / :388-389
             if (win.ensure(ip, lane)) st.invalidate();
             uint32_t r = ip - win.base;
-            if (r >= uni(st.cov_end)) st.gather(table, win, dup_scratch, r, kChunk, lane);
+            if (r >= uni(st.cov_end)) st.template gather<true>(table, win, dup_scratch, r, kChunk, lane);
             unsigned long long stopm = st.dup | st.longm;
 
             if (!((stopm >> r) & 1ull)) {
@@ -1090,6 +1095,7 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
                     skip += cnt;
                     if (p == kWave || ((stopm >> p) & 1ull)) {               // no hit at this stride level here
                         State::commit(table, win, pre, lane);                // (no DUP lane among them: those are stops)
+                        st.inserted |= pre;
                         ip += cnt * stride;
                         continue;
                     }
@@ -1117,6 +1123,7 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
                 if (why == 0 && (r > kWave || done)) endl &= ~(1ull << (r_end - 1));           // the last copy's is not (yet) due
                 C |= endl;
                 State::commit(table, win, C & ~st.dup, lane);
+                st.inserted |= C;
                 for (unsigned long long d = C & st.dup; d; d &= d - 1)                         // shared slots: in position order
                     State::commit(table, win, d & (~d + 1), lane);
 
@@ -1163,6 +1170,7 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
                 if (why == 0 && r > kWave) {                     // :391-392 for a copy that ended in a later window
                     if (win.ensure(ip - 1, lane)) st.invalidate();
                     State::commit(table, win, 1ull << (ip - 1 - win.base), lane);
+                    st.inserted |= 1ull << (ip - 1 - win.base);
                 }
                 continue;
             }
@@ -1170,27 +1178,32 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
             // ---------------- single step: DUP lane, long match, or stride > 1 ----------------
             uint32_t cand = 0, ext = 0;
             bool hit;
-            if (!((st.dup >> r) & 1ull)) {
-                State::commit(table, win, 1ull << r, lane);
+            // A DUP lane shares its hash with other lanes of the window.  If one of them (below r) has been inserted since
+            // the gather, the table slot holds the LATEST such lane j: candidate, hit test and match head all come from
+            // window registers.  Otherwise the gathered entry still stands, exactly as for a lane that shares nothing.
+            unsigned long long J = 0;
+            if ((st.dup >> r) & 1ull) {
+                const uint32_t hr = win.hash_at(ip);
+                J = __ballot(win.h0 == hr) & st.inserted & ((1ull << r) - 1ull);
+            }
+            State::commit(table, win, 1ull << r, lane);
+            st.inserted |= 1ull << r;
+            if (J) {
+                const uint32_t j = 63u - (uint32_t)__builtin_clzll(J);
+                cand = win.base + j;
+                hit = win.bytes_at(ip) == (uint32_t)__builtin_amdgcn_readlane((int)win.x0, (int)j);
+                if (hit) {
+                    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)st.xa, (int)r) ^
+                                        (uint32_t)__builtin_amdgcn_readlane((int)st.xa, (int)j);
+                    const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)st.xb, (int)r) ^
+                                        (uint32_t)__builtin_amdgcn_readlane((int)st.xb, (int)j);
+                    ext = d0 ? ((uint32_t)__builtin_ctz(d0) >> 3) : (d1 ? 4u + ((uint32_t)__builtin_ctz(d1) >> 3) : 8u);
+                }
+            } else {
                 hit = (st.hit >> r) & 1ull;
                 if (hit) {
                     cand = (uint32_t)__builtin_amdgcn_readlane((int)st.ent, (int)r) & 0xffffu;
                     ext = (uint32_t)__builtin_amdgcn_readlane((int)st.extv, (int)r);
-                }
-            } else {
-                // this lane shares its table slot with another lane of the window: ask the table itself
-                const uint32_t cur = win.bytes_at(ip);
-                const uint32_t mine = win.entry_at(ip);
-                const uint32_t old = table.exchange(win.hash_at(ip), mine, lane);
-                cand = old & 0xffffu;
-                hit = false;
-                if (!Table::certain_miss(old, mine)) {
-                    CandidateBytes cb;
-                    cb.fetch(base16, start + cand);
-                    if (cur == cb.c0) {
-                        ext = ext_from_candidate(win, ip, cb);
-                        hit = true;
-                    }
                 }
             }
             if (!hit) {
@@ -1208,6 +1221,7 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
             if (ip >= limit) break;                              // :388-389
             if (win.ensure(ip - 1, lane)) st.invalidate();
             State::commit(table, win, 1ull << (ip - 1 - win.base), lane);   // :391-392
+            st.inserted |= 1ull << (ip - 1 - win.base);
             skip = 31;
         }
     }
