@@ -99,10 +99,10 @@ constexpr int kVariantLdsTable = 1, kVariantGlobalTable = 3, kVariantLanePerBloc
 constexpr int kDefaultDecompressVariant = 1;   // the concurrent LDS+global form (2) measured no faster for K2
 constexpr int kDefaultK1Ahead = 64;     // look-ahead of the global-table form (64 = the whole cursor window)
 constexpr int kDefaultK1AheadLds = 64;  // look-ahead of the LDS-table form
-constexpr int kDefaultK1Form = 0;
-constexpr int kDefaultK1Filter = 0;
-constexpr int kDefaultK1FormLds = 0;
-constexpr int kDefaultLdsWaves = 1024;   // 4 LDS-table wavefronts per CU beside 28 global-table ones (measured best)
+constexpr int kDefaultK1Form = 2;       // bulk form for the global-table kernel
+constexpr int kDefaultK1Filter = 1;     // with the LDS slot filter
+constexpr int kDefaultK1FormLds = 2;    // bulk form for the LDS-table kernel
+constexpr int kDefaultLdsWaves = 512;   // 2 LDS-table wavefronts per CU (2 x 33 KiB) beside 30 global-table ones (3 KiB each: filter + duplicate test)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 
 // Work counters for persistent kernels: a small ring in the code object's own global memory, so launches need no

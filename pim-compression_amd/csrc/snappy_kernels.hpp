@@ -1248,6 +1248,11 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uin
     __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTableEntries];
     __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kForm ? kDupSlots : 16];
     const uint32_t lane = threadIdx.x;
+#ifndef SNAPPY_EMU
+    // The LDS-table wavefronts are few (LDS capacity) but cost no table traffic: let the instruction arbiter prefer them
+    // over the global-table wavefronts they share a SIMD with.
+    if (next_block) __builtin_amdgcn_s_setprio(3);
+#endif
     uint32_t b = blockIdx.x;
     for (;;) {
         if (next_block) {

@@ -285,7 +285,7 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
 
 uint64_t emu_compress(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_t* stream, uint64_t stream_cap)
 {
-    return emu_compress_variant(in, n, block_size, stream, stream_cap, 3);
+    return emu_compress_variant(in, n, block_size, stream, stream_cap, 12503);
 }
 
 // Runs index_streams_kernel + decompress_blocks_kernel on the emulator.

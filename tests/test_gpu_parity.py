@@ -203,34 +203,33 @@ def test_seeded_fuzz_vs_oracle(shb):
 
 # ---- every kernel variant produces the same bytes ------------------------------------------------------
 
+# K1 default = bulk form + slot filter (global-table kernel) beside the bulk LDS-table kernel; F0 = the windowed form
+F0 = {"SNAPPY_HIP_K1_FORM": "0", "SNAPPY_HIP_K1_FILTER": "0", "SNAPPY_HIP_K1_FORM_LDS": "0"}
+TINY_HYBRID = {"SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11", "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"}
+
+
 @pytest.mark.parametrize("env", [{"SNAPPY_HIP_COMPRESS_VARIANT": "1"}, {"SNAPPY_HIP_COMPRESS_VARIANT": "4"},
                                  {"SNAPPY_HIP_COMPRESS_VARIANT": "4", "SNAPPY_HIP_LANES_PER_BLOCK": "16"},
                                  {"SNAPPY_HIP_COMPRESS_VARIANT": "3", "SNAPPY_HIP_GT_WAVES": "7"},
                                  {"SNAPPY_HIP_COMPRESS_VARIANT": "5"},
                                  {"SNAPPY_HIP_COMPRESS_VARIANT": "5", "SNAPPY_HIP_GROUP_WAVES": "3"},
-                                 {"SNAPPY_HIP_LDS_WAVES": "0"},
-                                 {"SNAPPY_HIP_K1_AHEAD": "0"}, {"SNAPPY_HIP_K1_AHEAD": "4"}, {"SNAPPY_HIP_K1_AHEAD": "8"},
-                                 {"SNAPPY_HIP_K1_AHEAD": "16"}, {"SNAPPY_HIP_K1_AHEAD": "64"},
-                                 {"SNAPPY_HIP_K1_AHEAD": "8", "SNAPPY_HIP_COMPRESS_VARIANT": "1"},
-                                 {"SNAPPY_HIP_K1_FORM": "1", "SNAPPY_HIP_K1_AHEAD": "16"},
-                                 {"SNAPPY_HIP_K1_FORM": "1", "SNAPPY_HIP_K1_AHEAD": "32"},
-                                 {"SNAPPY_HIP_K1_FORM": "1", "SNAPPY_HIP_K1_AHEAD": "64", "SNAPPY_HIP_K1_FORM_LDS": "1",
-                                  "SNAPPY_HIP_K1_AHEAD_LDS": "64", "SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11",
-                                  "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"},
+                                 {"SNAPPY_HIP_LDS_WAVES": "0"}, TINY_HYBRID,
+                                 # windowed form: serial probes and look-ahead widths
+                                 {**F0, "SNAPPY_HIP_K1_AHEAD": "0", "SNAPPY_HIP_K1_AHEAD_LDS": "0"},
+                                 {**F0, "SNAPPY_HIP_K1_AHEAD": "8"}, {**F0, "SNAPPY_HIP_K1_AHEAD": "16"}, {**F0},
+                                 {**F0, "SNAPPY_HIP_LDS_WAVES": "1024"},
+                                 {**F0, "SNAPPY_HIP_K1_AHEAD_LDS": "8", "SNAPPY_HIP_COMPRESS_VARIANT": "1"},
+                                 {**F0, **TINY_HYBRID, "SNAPPY_HIP_K1_AHEAD": "16"},
+                                 {**F0, "SNAPPY_HIP_K1_FILTER": "1"},
+                                 # masked form
+                                 {"SNAPPY_HIP_K1_FORM": "1", "SNAPPY_HIP_K1_FILTER": "0", "SNAPPY_HIP_K1_AHEAD": "32"},
+                                 {"SNAPPY_HIP_K1_FORM": "1", "SNAPPY_HIP_K1_FORM_LDS": "1", **TINY_HYBRID},
+                                 {"SNAPPY_HIP_K1_FORM": "1"},
                                  {"SNAPPY_HIP_K1_FORM_LDS": "1", "SNAPPY_HIP_K1_AHEAD_LDS": "32", "SNAPPY_HIP_COMPRESS_VARIANT": "1"},
-                                 {"SNAPPY_HIP_K1_FORM": "2", "SNAPPY_HIP_K1_AHEAD": "16"},
-                                 {"SNAPPY_HIP_K1_FORM": "2", "SNAPPY_HIP_K1_AHEAD": "32"},
-                                 {"SNAPPY_HIP_K1_FORM": "2", "SNAPPY_HIP_K1_AHEAD": "64", "SNAPPY_HIP_K1_FORM_LDS": "2",
-                                  "SNAPPY_HIP_K1_AHEAD_LDS": "64", "SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11",
-                                  "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"},
-                                 {"SNAPPY_HIP_K1_FORM_LDS": "2", "SNAPPY_HIP_K1_AHEAD_LDS": "32", "SNAPPY_HIP_COMPRESS_VARIANT": "1"},
-                                 {"SNAPPY_HIP_K1_FILTER": "1"}, {"SNAPPY_HIP_K1_FILTER": "1", "SNAPPY_HIP_K1_FORM": "1"},
-                                 {"SNAPPY_HIP_K1_FILTER": "1", "SNAPPY_HIP_K1_FORM": "2", "SNAPPY_HIP_LDS_WAVES": "0"},
-                                 {"SNAPPY_HIP_K1_FILTER": "1", "SNAPPY_HIP_K1_FORM": "2", "SNAPPY_HIP_K1_AHEAD": "32",
-                                  "SNAPPY_HIP_LDS_WAVES": "3", "SNAPPY_HIP_GT_WAVES": "9", "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"},
-                                 {"SNAPPY_HIP_K1_AHEAD": "4", "SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11",
-                                  "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"},
-                                 {"SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11", "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"},
+                                 # bulk form: without filter, narrower chunks, alone
+                                 {"SNAPPY_HIP_K1_FILTER": "0"}, {"SNAPPY_HIP_K1_FILTER": "0", "SNAPPY_HIP_K1_AHEAD": "32"},
+                                 {"SNAPPY_HIP_K1_AHEAD": "32", **TINY_HYBRID},
+                                 {"SNAPPY_HIP_K1_AHEAD_LDS": "32", "SNAPPY_HIP_COMPRESS_VARIANT": "1"},
                                  {"SNAPPY_HIP_DECOMPRESS_VARIANT": "0"},
                                  {"SNAPPY_HIP_DECOMPRESS_VARIANT": "2", "SNAPPY_HIP_K2_LDS_WAVES": "3",
                                   "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"}])
