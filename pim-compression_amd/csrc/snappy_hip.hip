@@ -187,8 +187,15 @@ void launch_k1_global_filtered(uint32_t grid, hipStream_t st, const uint8_t* d_i
                                uint8_t* d_slots, uint32_t slot_stride, uint32_t* d_block_bytes, uint32_t nb, uint32_t* tables,
                                uint32_t* counter)
 {
-    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<kAhead, kForm, true>), dim3(grid), dim3(64), 0, st, d_in,
+    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<kAhead, kForm, 1>), dim3(grid), dim3(64), 0, st, d_in,
                        input_len, block_size, d_slots, slot_stride, d_block_bytes, nb, tables, counter);
+}
+inline void launch_k1_global_class_filtered(uint32_t grid, hipStream_t st, const uint8_t* d_in, uint64_t input_len,
+                                            uint32_t block_size, uint8_t* d_slots, uint32_t slot_stride, uint32_t* d_block_bytes,
+                                            uint32_t nb, uint32_t* tables, uint32_t* counter)
+{
+    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 2, 2>), dim3(grid), dim3(64), 0, st, d_in, input_len,
+                       block_size, d_slots, slot_stride, d_block_bytes, nb, tables, counter);
 }
 #define SNAPPY_K1_DISPATCH_FILTERED(ahead, form, ...)                                   \
     do {                                                                                \
@@ -329,7 +336,7 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
     const int k1_ahead_lds = env_int("SNAPPY_HIP_K1_AHEAD_LDS", kDefaultK1AheadLds);
     const int k1_masked = env_int("SNAPPY_HIP_K1_FORM", kDefaultK1Form);          // 0 windowed, 1 masked, 2 bulk
     const int k1_masked_lds = env_int("SNAPPY_HIP_K1_FORM_LDS", kDefaultK1FormLds);
-    const bool k1_filter = env_int("SNAPPY_HIP_K1_FILTER", kDefaultK1Filter) != 0;
+    const int k1_filter = env_int("SNAPPY_HIP_K1_FILTER", kDefaultK1Filter);   // 0 none, 1 written bit, 2 tag class (bulk, look-ahead 64)
     const dim3 grid((uint32_t)nb), block(64);
     hipStream_t st = (hipStream_t)stream;
     if (variant == kVariantGroup) {
@@ -388,7 +395,9 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
             SNAPPY_K1_DISPATCH(launch_k1_lds, k1_ahead_lds, k1_masked_lds, lds_waves, 0u, helper, d_in, input_len, block_size, d_slots, slot_stride,
                                d_block_bytes, (uint32_t)nb, counter);
             HIP_TRY(hipEventRecord(ev_end, helper));
-            if (k1_filter)
+            if (k1_filter == 2)
+                launch_k1_global_class_filtered(g, st, d_in, input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);
+            else if (k1_filter)
                 SNAPPY_K1_DISPATCH_FILTERED(k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride,
                                             d_block_bytes, (uint32_t)nb, tables, counter);
             else
@@ -396,7 +405,9 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
                                    d_block_bytes, (uint32_t)nb, tables, counter);
             HIP_TRY(hipStreamWaitEvent(st, ev_end, 0));                // the caller's stream resumes when both are done
         } else {
-            if (k1_filter)
+            if (k1_filter == 2)
+                launch_k1_global_class_filtered(g, st, d_in, input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);
+            else if (k1_filter)
                 SNAPPY_K1_DISPATCH_FILTERED(k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride,
                                             d_block_bytes, (uint32_t)nb, tables, counter);
             else

@@ -284,12 +284,17 @@ struct CandidateBytes {
 typedef volatile uint8_t* lds_bytes_t;
 typedef volatile uint32_t* lds_words_t;
 __device__ __forceinline__ void lds_or(lds_words_t p, uint32_t v) { *p = *p | v; }
+__device__ __forceinline__ void lds_and(lds_words_t p, uint32_t v) { *p = *p & v; }
 #else
 typedef volatile __attribute__((address_space(3))) uint8_t* lds_bytes_t;
 typedef volatile __attribute__((address_space(3))) uint32_t* lds_words_t;
 __device__ __forceinline__ void lds_or(lds_words_t p, uint32_t v)
 {
     __hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ void lds_and(lds_words_t p, uint32_t v)
+{
+    __hip_atomic_fetch_and((__attribute__((address_space(3))) uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 #endif
 
@@ -328,7 +333,7 @@ struct TaggedGlobalTable {      // u32 entries in the global scratch: tag << 16 
     // true when the candidate stored in `old` can be skipped without looking at its bytes
     __device__ __forceinline__ static bool certain_miss(uint32_t old, uint32_t entry) { return ((old ^ entry) >> 16) != 0; }
     // per-lane (divergent index) accessors for the look-ahead gather
-    __device__ __forceinline__ uint32_t load_lane(uint32_t h) const { return t[h]; }
+    __device__ __forceinline__ uint32_t load_lane(uint32_t h, uint32_t = 0) const { return t[h]; }
     __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const { t[h] = entry; }
     __device__ __forceinline__ TaggedGlobalTable with_empty(uint32_t) const { return *this; }
 };
@@ -370,13 +375,74 @@ struct FilteredGlobalTable {
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ static bool certain_miss(uint32_t old, uint32_t entry) { return ((old ^ entry) >> 16) != 0; }
-    __device__ __forceinline__ uint32_t load_lane(uint32_t h) const { return is_written(h) ? t[h] : empty; }
+    __device__ __forceinline__ uint32_t load_lane(uint32_t h, uint32_t = 0) const { return is_written(h) ? t[h] : empty; }
     __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const
     {
         t[h] = entry;
         lds_or(written + (h >> 5), 1u << (h & 31u));
     }
     __device__ __forceinline__ FilteredGlobalTable with_empty(uint32_t e) const { return FilteredGlobalTable{t, written, e}; }
+};
+
+// FilteredGlobalTable with two bits per slot (4 KiB of LDS per wavefront): 0 = not written in this block, 1..3 = a class of
+// the 16-bit content tag of the entry the slot holds.  A probe whose own tag falls in a different class cannot match that
+// entry (different tag => different 4 bytes, a certain miss in :348 / :398), so its table line is not read either; the
+// caller gets an entry with the complemented tag, which certain_miss() rejects.  About 60 % of the probes of written
+// slots end here.
+struct ClassFilteredGlobalTable {
+    uint32_t* __restrict__ t;
+    lds_words_t cls;            // kMaxTableEntries / 16 words
+    uint32_t empty;             // tag(position 0) << 16 | 0
+    __device__ __forceinline__ static uint32_t class_of(uint32_t entry)
+    {
+        const uint32_t two = (entry >> 16) & 3u;
+        return 1u + (two < 2u ? two : 2u);
+    }
+    __device__ __forceinline__ void init(uint32_t entries, uint32_t, uint32_t lane) const
+    {
+        for (uint32_t i = lane; i < entries / 16; i += kWave) cls[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ uint32_t slot_class(uint32_t h) const { return (cls[h >> 4] >> ((h & 15u) * 2u)) & 3u; }
+    __device__ __forceinline__ void set_class(uint32_t h, uint32_t entry) const
+    {
+        const uint32_t sh = (h & 15u) * 2u;
+        lds_and(cls + (h >> 4), ~(3u << sh));
+        lds_or(cls + (h >> 4), class_of(entry) << sh);
+    }
+    // what a probe carrying `probe_entry` needs to know about slot h
+    __device__ __forceinline__ uint32_t load_lane(uint32_t h, uint32_t probe_entry) const
+    {
+        const uint32_t c = slot_class(h);
+        if (c == 0) return empty;
+        if (c != class_of(probe_entry)) return ~probe_entry & 0xffff0000u;     // some other tag: a certain miss
+        return t[h];
+    }
+    __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const
+    {
+        t[h] = entry;
+        set_class(h, entry);
+    }
+    __device__ __forceinline__ uint32_t exchange(uint32_t h, uint32_t entry, uint32_t lane) const
+    {
+        uint32_t hv = h;
+        SNAPPY_PIN(hv);
+        const uint32_t old = uni(load_lane(hv, entry));
+        t[hv] = entry;
+        if (lane == 0) set_class(h, entry);
+        __builtin_amdgcn_wave_barrier();
+        return old;
+    }
+    __device__ __forceinline__ void put(uint32_t h, uint32_t entry, uint32_t lane) const
+    {
+        uint32_t hv = h;
+        SNAPPY_PIN(hv);
+        t[hv] = entry;
+        if (lane == 0) set_class(h, entry);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ static bool certain_miss(uint32_t old, uint32_t entry) { return ((old ^ entry) >> 16) != 0; }
+    __device__ __forceinline__ ClassFilteredGlobalTable with_empty(uint32_t e) const { return ClassFilteredGlobalTable{t, cls, e}; }
 };
 
 struct LdsTable {               // the reference's own layout: u16 positions, in LDS (no room for tags: 32 KiB per block)
@@ -399,7 +465,7 @@ struct LdsTable {               // the reference's own layout: u16 positions, in
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ static bool certain_miss(uint32_t, uint32_t) { return false; }
-    __device__ __forceinline__ uint32_t load_lane(uint32_t h) const { return t[h]; }
+    __device__ __forceinline__ uint32_t load_lane(uint32_t h, uint32_t = 0) const { return t[h]; }
     __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const { t[h] = (uint16_t)entry; }
     __device__ __forceinline__ LdsTable with_empty(uint32_t) const { return *this; }
 };
@@ -475,8 +541,8 @@ struct EntryCache {
                                            uint32_t lane)
     {
         const bool g = lane >= r && lane < r + span;
-        if (g) ent = table.load_lane(win.h0);
         const uint32_t mine_l = win.e0 | (win.base + lane);
+        if (g) ent = table.load_lane(win.h0, mine_l);
         const bool worth = g && !Table::certain_miss(ent, mine_l);
         if (worth) {                                  // every stored position p has p + 16 <= block length
             const uint8_t* __restrict__ c = win.blk + (ent & 0xffffu);
@@ -746,8 +812,8 @@ struct MaskedWindowState {
         const uint32_t e = (r + span < kWave) ? r + span : kWave;
         const unsigned long long gm = kWithDup ? lane_range(r, e - r) : (lane_range(r, e - r) & ~dup);
         const bool g = __builtin_amdgcn_inverse_ballot_w64(gm);
-        if (g) ent = table.load_lane(win.h0);
         const uint32_t mine_l = win.e0 | (win.base + lane);
+        if (g) ent = table.load_lane(win.h0, mine_l);
         const bool worth = g && !Table::certain_miss(ent, mine_l);
         uint32_t k0 = 0, k1 = 0, k2 = 0;
         if (worth) {                                  // every stored position p has p + 16 <= block length
@@ -1064,13 +1130,14 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
             if (r >= uni(st.cov_end)) st.template gather<true>(table, win, dup_scratch, r, kChunk, lane);
             unsigned long long stopm = st.dup | st.longm;
 
-            if (!((stopm >> r) & 1ull)) {
+            bool need_single = true;
+            if (stride <= 1 || !((stopm >> r) & 1ull)) {
                 // ---------------- segment ----------------
                 uint32_t hi = uni(st.cov_end);
                 const uint32_t lim = limit - win.base;           // lanes below may be probed (position + 1 <= limit)
                 hi = lim < hi ? lim : hi;
                 if (hi < kWave) stopm |= ~0ull << hi;
-                const unsigned long long inter = st.hit | stopm;
+                unsigned long long inter = st.hit | stopm;
                 unsigned long long pre = 0;                      // lanes probed by the strided prefix
                 uint32_t B = 64u - skip;                         // stride-1 probes left before :339 widens the stride
                 if (stride > 1) {
@@ -1104,7 +1171,55 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
                 }
                 const uint32_t r0 = r;
                 unsigned long long H = 0, COV = 0;
-                const uint32_t why = segment_walk(inter, stopm, 4u + st.extv, hi, r, B, H, COV);
+                uint32_t why;
+                need_single = false;
+                for (;;) {
+                    why = segment_walk(inter, stopm, 4u + st.extv, hi, r, B, H, COV);
+                    if (why != 2 || r >= hi) break;
+                    // The walk stands on a DUP lane or on a hit of 12+ bytes.  Settle that one probe here -- from registers
+                    // for a DUP lane, with the 64-lane extender for a long match -- patch the lane's cached entry / match
+                    // length, and let the walk go on: the segment, its one table commit and its one emission continue.
+                    bool hit_r;
+                    uint32_t cand_r, ext_r;
+                    if ((st.dup >> r) & 1ull) {
+                        const uint32_t hr = (uint32_t)__builtin_amdgcn_readlane((int)win.h0, (int)r);
+                        const unsigned long long inner = COV & ~H;
+                        const unsigned long long so_far = st.inserted | pre | (((~0ull << r0) & ((1ull << r) - 1ull)) & ~inner) |
+                                                          (COV & ~(inner >> 1));
+                        const unsigned long long J = __ballot(win.h0 == hr) & so_far & ((1ull << r) - 1ull);
+                        if (J) {                                 // the slot holds the latest inserted lane with this hash
+                            const uint32_t j = 63u - (uint32_t)__builtin_clzll(J);
+                            cand_r = win.base + j;
+                            hit_r = (uint32_t)__builtin_amdgcn_readlane((int)win.x0, (int)r) ==
+                                    (uint32_t)__builtin_amdgcn_readlane((int)win.x0, (int)j);
+                            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)st.xa, (int)r) ^
+                                                (uint32_t)__builtin_amdgcn_readlane((int)st.xa, (int)j);
+                            const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)st.xb, (int)r) ^
+                                                (uint32_t)__builtin_amdgcn_readlane((int)st.xb, (int)j);
+                            ext_r = d0 ? ((uint32_t)__builtin_ctz(d0) >> 3) : (d1 ? 4u + ((uint32_t)__builtin_ctz(d1) >> 3) : 8u);
+                        } else {                                 // nothing inserted since the gather: its result stands
+                            hit_r = (st.hit >> r) & 1ull;
+                            cand_r = (uint32_t)__builtin_amdgcn_readlane((int)st.ent, (int)r) & 0xffffu;
+                            ext_r = (uint32_t)__builtin_amdgcn_readlane((int)st.extv, (int)r);
+                        }
+                    } else {                                     // a resolved hit whose first 12 bytes match
+                        hit_r = true;
+                        cand_r = (uint32_t)__builtin_amdgcn_readlane((int)st.ent, (int)r) & 0xffffu;
+                        ext_r = 8;
+                    }
+                    uint32_t len_r = 4u + ext_r;
+                    if (hit_r && ext_r == 8) len_r = 12u + match_extend(blk, cand_r + 12, win.base + r + 12, n, lane);
+                    if (hit_r && len_r > 63u) {                  // more than one copy element (:254-272): single step below
+                        need_single = true;
+                        break;
+                    }
+                    if (lane == r) {
+                        st.extv = len_r - 4u;
+                        st.ent = cand_r;
+                    }
+                    stopm &= ~(1ull << r);
+                    inter = hit_r ? (inter | (1ull << r)) : (inter & ~(1ull << r));
+                }
                 if (why == 1) {                                  // B (or all remaining) lanes of misses
                     const uint32_t room = hi - r;
                     const uint32_t adv = B < room ? B : room;
@@ -1118,7 +1233,8 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
 
                 // ---- table: every probed lane (:346-347, :397) and every "ip - 1" lane (:391-392) inserts its position ----
                 const unsigned long long interior = COV & ~H;
-                unsigned long long C = pre | (((~0ull << r0) & lanes_below(r_end)) & ~interior);   // probed lanes
+                const unsigned long long walked = r_end > r0 ? ((~0ull << r0) & lanes_below(r_end)) : 0ull;   // may be empty
+                unsigned long long C = pre | (walked & ~interior);                                  // probed lanes
                 unsigned long long endl = COV & ~(interior >> 1);                              // last lane of each copy
                 if (why == 0 && (r > kWave || done)) endl &= ~(1ull << (r_end - 1));           // the last copy's is not (yet) due
                 C |= endl;
@@ -1143,7 +1259,8 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
                     const uint32_t off = win.base + lane - (st.ent & 0xffffu);  // meaningful in H lanes
                     const uint32_t len = 4u + st.extv;
                     const bool is_hit = __builtin_amdgcn_inverse_ballot_w64(H);
-                    const unsigned long long H3 = __ballot(is_hit && off >= 2048u);
+                    const bool three = off >= 2048u || len >= 12u;                 // :234-245
+                    const unsigned long long H3 = __ballot(is_hit && three);
                     uint32_t P = mbcnt64(H, 0);
                     P = mbcnt64(LIT, op + 2u * P);
                     P = mbcnt64(H3, P);
@@ -1156,11 +1273,11 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
                     }
                     if (is_hit) {
                         uint32_t b0;
-                        if (off < 2048u) b0 = 1u + ((len - 4u) << 2) + ((off >> 8) << 5);   // :234-239
+                        if (!three) b0 = 1u + ((len - 4u) << 2) + ((off >> 8) << 5);        // :234-239
                         else b0 = 2u + ((len - 1u) << 2);                                   // :240-245
                         dst[P] = (uint8_t)b0;
                         dst[P + 1] = (uint8_t)off;
-                        if (off >= 2048u) dst[P + 2] = (uint8_t)(off >> 8);
+                        if (three) dst[P + 2] = (uint8_t)(off >> 8);
                     }
                     op += (uint32_t)__builtin_popcountll(LIT) + 2u * (uint32_t)__builtin_popcountll(H) +
                           (uint32_t)__builtin_popcountll(H3) + (uint32_t)__builtin_popcountll(LS);
@@ -1172,7 +1289,8 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
                     State::commit(table, win, 1ull << (ip - 1 - win.base), lane);
                     st.inserted |= 1ull << (ip - 1 - win.base);
                 }
-                continue;
+                if (!need_single) continue;
+                r = ip - win.base;                               // a copy of 64+ bytes starts here
             }
 
             // ---------------- single step: DUP lane, long match, or stride > 1 ----------------
@@ -1281,7 +1399,7 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uin
     }
 }
 
-template <uint32_t kAhead, int kForm = 0, bool kFilter = false>
+template <uint32_t kAhead, int kForm = 0, int kFilter = 0>
 __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
                                                                           uint32_t block_size, uint8_t* __restrict__ slots,
                                                                           uint32_t slot_stride,
@@ -1290,13 +1408,18 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
                                                                           uint32_t* next_block)
 {
     __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kForm ? kDupSlots : 16];
-    __shared__ __attribute__((aligned(16))) uint32_t slot_written[kFilter ? kMaxTableEntries / 32 : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t slot_state[kFilter == 2 ? kMaxTableEntries / 16 : (kFilter ? kMaxTableEntries / 32 : 4)];
     const uint32_t lane = threadIdx.x;
-    using Table = typename std::conditional<kFilter, FilteredGlobalTable, TaggedGlobalTable>::type;
+    using Table = typename std::conditional<kFilter == 2, ClassFilteredGlobalTable,
+                                            typename std::conditional<kFilter == 1, FilteredGlobalTable, TaggedGlobalTable>::type>::type;
     Table table;
     table.t = table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
-    if constexpr (kFilter) {
-        table.written = (lds_words_t)slot_written;
+    if constexpr (kFilter == 1) {
+        table.written = (lds_words_t)slot_state;
+        table.empty = 0;
+    }
+    if constexpr (kFilter == 2) {
+        table.cls = (lds_words_t)slot_state;
         table.empty = 0;
     }
     for (;;) {

@@ -188,7 +188,7 @@ extern "C" {
 // Runs compress_blocks_kernel + scan + gather on the CPU emulator.  Returns stream length.
 // variant = kernel form (1 LDS table, 3 global table, 4 lane-per-block, 5 group) + 100 * look-ahead code
 // (0 = EMU_K1_AHEAD, 1 = off, 2 = 4, 3 = 8, 4 = 16, 5 = 64) + 1000 for the masked form, + 2000 for the bulk form (chunk = look-ahead, needs > 0),
-// + 10000 for the LDS slot filter in front of the global table
+// + 10000 for the LDS slot filter in front of the global table, + 20000 for the tag-class filter (bulk form only)
 #define EMU_AHEAD_DISPATCH(code, CALL)                         \
     switch (code) {                                            \
     case 1: { constexpr uint32_t kA = 0; CALL; } break;        \
@@ -201,7 +201,8 @@ extern "C" {
 
 uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_t* stream, uint64_t stream_cap, int variant)
 {
-    const bool filtered = variant >= 10000;
+    const int filter_kind = variant / 10000;     // 1 = written bit, 2 = tag class
+    const bool filtered = filter_kind != 0;
     variant %= 10000;
     const int form = variant / 1000;
     const bool masked = form != 0;
@@ -226,15 +227,18 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
         std::vector<uint32_t> tables((size_t)grid * 16384, 0xBEEFBEEFu);
         uint32_t counter = 0;
         emu::launch(grid, 64, [&] {
-            if (filtered) {
+            if (filter_kind == 2) {
+                EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 2, 2>(
+                                                   inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter)));
+            } else if (filtered) {
                 if (form == 2) {
-                    EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 2, true>(
+                    EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 2, 1>(
                                                        inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter)));
                 } else if (form == 1) {
-                    EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 1, true>(
+                    EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 1, 1>(
                                                        inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter)));
                 } else {
-                    EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<kA, 0, true>(
+                    EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<kA, 0, 1>(
                                                        inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter)));
                 }
             } else if (form == 2) {

@@ -230,6 +230,7 @@ TINY_HYBRID = {"SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11", "SNAPPY
                                  {"SNAPPY_HIP_K1_FILTER": "0"}, {"SNAPPY_HIP_K1_FILTER": "0", "SNAPPY_HIP_K1_AHEAD": "32"},
                                  {"SNAPPY_HIP_K1_AHEAD": "32", **TINY_HYBRID},
                                  {"SNAPPY_HIP_K1_AHEAD_LDS": "32", "SNAPPY_HIP_COMPRESS_VARIANT": "1"},
+                                 {"SNAPPY_HIP_K1_FILTER": "2", "SNAPPY_HIP_LDS_WAVES": "0"}, {"SNAPPY_HIP_K1_FILTER": "2", **TINY_HYBRID},
                                  {"SNAPPY_HIP_DECOMPRESS_VARIANT": "0"},
                                  {"SNAPPY_HIP_DECOMPRESS_VARIANT": "2", "SNAPPY_HIP_K2_LDS_WAVES": "3",
                                   "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"}])
