@@ -102,7 +102,7 @@ constexpr int kDefaultK1AheadLds = 64;  // look-ahead of the LDS-table form
 constexpr int kDefaultK1Form = 2;       // bulk form for the global-table kernel
 constexpr int kDefaultK1Filter = 1;     // with the LDS slot filter
 constexpr int kDefaultK1FormLds = 2;    // bulk form for the LDS-table kernel
-constexpr int kDefaultLdsWaves = 512;   // 2 LDS-table wavefronts per CU (2 x 33 KiB) beside 30 global-table ones (3 KiB each: filter + duplicate test)
+constexpr int kDefaultLdsWaves = 768;   // 3 LDS-table wavefronts per CU (3 x 33 KiB) beside 20 global-table ones (3 KiB each: filter + duplicate test)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 
 // Work counters for persistent kernels: a small ring in the code object's own global memory, so launches need no
@@ -374,7 +374,23 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
                            d_block_bytes, (uint32_t)nb, (uint32_t*)nullptr);
     } else {
         // persistent grid, blocks handed out by an atomic counter kept in the first bytes of the scratch
-        uint32_t waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", kGlobalTableWaves);
+        // Wave budget per CU (256 CUs, 32 wave slots, 160 KiB of LDS each): the LDS-table wavefronts hold a 32 KiB table
+        // (+ 1 KiB duplicate test in the masked / bulk forms); a global-table wavefront holds the duplicate test (1 KiB)
+        // and the slot filter (2 KiB, or 4 KiB with tag classes).  SNAPPY_HIP_GT_WAVES overrides the TOTAL of both kinds.
+        uint32_t waves = kGlobalTableWaves;
+        {
+            const uint32_t lds_req = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", kDefaultLdsWaves);
+            const uint32_t lds_per_cu = (lds_req + 255u) / 256u;
+            const uint32_t lds_wave_kib = 32u + (k1_masked_lds ? 1u : 0u);
+            const uint32_t g_wave_kib = (k1_masked ? 1u : 0u) + (k1_filter == 2 ? 4u : (k1_filter ? 2u : 0u));
+            uint32_t g_per_cu = 32u > lds_per_cu ? 32u - lds_per_cu : 0u;
+            if (g_wave_kib && lds_per_cu * lds_wave_kib < 160u) {
+                const uint32_t fit = (160u - lds_per_cu * lds_wave_kib) / g_wave_kib;
+                g_per_cu = fit < g_per_cu ? fit : g_per_cu;
+            }
+            waves = lds_req + g_per_cu * 256u;
+        }
+        waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", (int)waves);
         if (waves > kGlobalTableWaves) waves = kGlobalTableWaves;
         uint32_t* counter = static_cast<uint32_t*>(d_scratch);
         uint32_t* tables = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_scratch) + 256);

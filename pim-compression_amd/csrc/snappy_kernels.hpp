@@ -777,7 +777,8 @@ struct MaskedWindowState {
     uint32_t extv = 0;              // per lane: matching bytes among the 8 after the 4-byte key (0..8), for HIT lanes
     unsigned long long hit = 0;     // wave-uniform: lanes whose probe would hit
     unsigned long long dup = 0;     // wave-uniform: lanes that must not use the cache
-    unsigned long long longm = 0;   // wave-uniform: HIT lanes with extv == 8
+    unsigned long long longm = 0;   // wave-uniform: HIT lanes whose extv is saturated (the match goes on)
+    unsigned long long deepm = 0;   // wave-uniform: lanes whose extv covers 24 bytes (saturates at 24) instead of 8
     unsigned long long inserted = 0;// wave-uniform: window lanes whose position has been inserted (bulk form)
     uint32_t xa = 0, xb = 0;        // per lane: le32 at position + 4 / + 8
     uint32_t cov_end = 0;           // lanes in [gather start, cov_end) are resolved
@@ -801,9 +802,11 @@ struct MaskedWindowState {
     }
 
     // kWithDup: also read the slots of DUP lanes (their values hold only while no same-hash lane of the window is inserted)
-    template <bool kWithDup = false>
+    // kDeep: compare 28 candidate bytes instead of 12 (where the block has that many), so that matches of up to 27 bytes
+    // are fully sized by the gather
+    template <bool kWithDup = false, bool kDeep = false>
     __device__ __forceinline__ void gather(const Table& table, const CursorWindow& win, lds_bytes_t scratch, uint32_t r,
-                                           uint32_t span, uint32_t lane)
+                                           uint32_t span, uint32_t lane, uint32_t block_len = 0)
     {
         if (!dup_valid) {
             dup = dup_slot_lanes(scratch, win.h0, lane);
@@ -816,19 +819,41 @@ struct MaskedWindowState {
         if (g) ent = table.load_lane(win.h0, mine_l);
         const bool worth = g && !Table::certain_miss(ent, mine_l);
         uint32_t k0 = 0, k1 = 0, k2 = 0;
+        const bool deep = kDeep && worth && (win.base + lane + 28u <= block_len);   // candidate < position, so it has 28 too
+        uint32_t k3 = 0, k4 = 0, k5 = 0, k6 = 0, o3 = 1, o4 = 1, o5 = 1, o6 = 1;
         if (worth) {                                  // every stored position p has p + 16 <= block length
             const uint8_t* __restrict__ c = win.blk + (ent & 0xffffu);
             k0 = ld32(c);
             k1 = ld32(c + 4);
             k2 = ld32(c + 8);
+            if (deep) {
+                k3 = ld32(c + 12);
+                k4 = ld32(c + 16);
+                k5 = ld32(c + 20);
+                k6 = ld32(c + 24);
+                const uint8_t* __restrict__ o = win.blk + win.base + lane;
+                o3 = ld32(o + 12);
+                o4 = ld32(o + 16);
+                o5 = ld32(o + 20);
+                o6 = ld32(o + 24);
+            }
         }
         xa = bytes_ahead(win, lane, 4);
         xb = bytes_ahead(win, lane, 8);
         const uint32_t d0 = k1 ^ xa, d1 = k2 ^ xb;
         extv = d0 ? ((uint32_t)__builtin_ctz(d0) >> 3) : (d1 ? 4u + ((uint32_t)__builtin_ctz(d1) >> 3) : 8u);
+        if (kDeep) {
+            if (deep && extv == 8) {
+                const uint32_t d3 = k3 ^ o3, d4 = k4 ^ o4, d5 = k5 ^ o5, d6 = k6 ^ o6;
+                extv = d3 ? 8u + ((uint32_t)__builtin_ctz(d3) >> 3)
+                          : (d4 ? 12u + ((uint32_t)__builtin_ctz(d4) >> 3)
+                                : (d5 ? 16u + ((uint32_t)__builtin_ctz(d5) >> 3) : (d6 ? 20u + ((uint32_t)__builtin_ctz(d6) >> 3) : 24u)));
+            }
+            deepm = __ballot(deep);
+        }
         const bool hitl = worth && k0 == win.x0;
         hit = __ballot(hitl);                          // lanes below r are behind the cursor, lanes >= e not covered
-        longm = __ballot(hitl && extv == 8);           // hits whose match goes on past 12 bytes
+        longm = __ballot(hitl && extv == (deep ? 24u : 8u));   // hits whose match goes on past the compared bytes
         cov_end = e;
     }
 
@@ -1022,7 +1047,7 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t add)
 __device__ __forceinline__ unsigned long long lanes_below(uint32_t n) { return ~0ull >> (64u - n); }
 
 // The walk of one segment.  `inter` = HIT | stop lanes (stop = DUP, long matches, and every lane >= hi), `lenv` = per-lane
-// match length for HIT lanes (4..11), r < hi <= 64 the cursor lane, B the number of stride-1 probes still allowed (:339).
+// match length for HIT lanes (4..63), r < hi <= 64 the cursor lane, B the number of stride-1 probes still allowed (:339).
 // Per match: skip the misses (first set bit of inter), take the hit (H), cover its lanes (COV), continue behind it.
 // Returns why it stopped: 0 = behind a copy at a lane >= hi, 1 = no hit within the next B lanes (r NOT advanced),
 // 2 = r is a stop lane (not probed).  On gfx950 this is 16 instructions per match, hand-scheduled; the C++ body is
@@ -1127,7 +1152,7 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
             if (ip + step > limit) break;                        // :342-343 / :388-389
             if (win.ensure(ip, lane)) st.invalidate();
             uint32_t r = ip - win.base;
-            if (r >= uni(st.cov_end)) st.template gather<true>(table, win, dup_scratch, r, kChunk, lane);
+            if (r >= uni(st.cov_end)) st.template gather<true, true>(table, win, dup_scratch, r, kChunk, lane, n);
             unsigned long long stopm = st.dup | st.longm;
 
             bool need_single = true;
@@ -1181,6 +1206,7 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
                     // length, and let the walk go on: the segment, its one table commit and its one emission continue.
                     bool hit_r;
                     uint32_t cand_r, ext_r;
+                    uint32_t sat_r = 8;                          // where ext_r saturates: 8, or 24 for a deep lane's own result
                     if ((st.dup >> r) & 1ull) {
                         const uint32_t hr = (uint32_t)__builtin_amdgcn_readlane((int)win.h0, (int)r);
                         const unsigned long long inner = COV & ~H;
@@ -1201,14 +1227,17 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
                             hit_r = (st.hit >> r) & 1ull;
                             cand_r = (uint32_t)__builtin_amdgcn_readlane((int)st.ent, (int)r) & 0xffffu;
                             ext_r = (uint32_t)__builtin_amdgcn_readlane((int)st.extv, (int)r);
+                            sat_r = ((st.deepm >> r) & 1ull) ? 24u : 8u;
                         }
-                    } else {                                     // a resolved hit whose first 12 bytes match
+                    } else {                                     // a resolved hit whose compared bytes all match
                         hit_r = true;
                         cand_r = (uint32_t)__builtin_amdgcn_readlane((int)st.ent, (int)r) & 0xffffu;
-                        ext_r = 8;
+                        sat_r = ((st.deepm >> r) & 1ull) ? 24u : 8u;
+                        ext_r = sat_r;
                     }
                     uint32_t len_r = 4u + ext_r;
-                    if (hit_r && ext_r == 8) len_r = 12u + match_extend(blk, cand_r + 12, win.base + r + 12, n, lane);
+                    if (hit_r && ext_r == sat_r)
+                        len_r = 4u + sat_r + match_extend(blk, cand_r + 4u + sat_r, win.base + r + 4u + sat_r, n, lane);
                     if (hit_r && len_r > 63u) {                  // more than one copy element (:254-272): single step below
                         need_single = true;
                         break;
@@ -1294,7 +1323,7 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
             }
 
             // ---------------- single step: DUP lane, long match, or stride > 1 ----------------
-            uint32_t cand = 0, ext = 0;
+            uint32_t cand = 0, ext = 0, sat = 8;
             bool hit;
             // A DUP lane shares its hash with other lanes of the window.  If one of them (below r) has been inserted since
             // the gather, the table slot holds the LATEST such lane j: candidate, hit test and match head all come from
@@ -1322,6 +1351,7 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
                 if (hit) {
                     cand = (uint32_t)__builtin_amdgcn_readlane((int)st.ent, (int)r) & 0xffffu;
                     ext = (uint32_t)__builtin_amdgcn_readlane((int)st.extv, (int)r);
+                    sat = ((st.deepm >> r) & 1ull) ? 24u : 8u;
                 }
             }
             if (!hit) {
@@ -1332,7 +1362,7 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
             if (ip > next_emit) op = emit_literal_windowed(dst, op, blk, next_emit, ip - next_emit, win.base, win.x0, lane);   // :355
             const uint32_t mbase = ip;
             uint32_t matched = 4 + ext;                          // find_match_length (:176-193)
-            if (ext == 8) matched = 12 + match_extend(blk, cand + 12, ip + 12, n, lane);
+            if (ext == sat) matched = 4 + sat + match_extend(blk, cand + 4 + sat, ip + 4 + sat, n, lane);
             ip += matched;
             op = emit_copy_packed(dst, op, mbase - cand, matched, lane);
             next_emit = ip;
