@@ -92,8 +92,17 @@ class Batch:
         self.status = torch.empty(self.nb, dtype=torch.int32, device="cuda")
         self.out = torch.empty(container_len + 16, dtype=torch.uint8, device="cuda")
         self.kernel_events = {"compress": [], "decompress": []}
-        self.side_stream = torch.cuda.Stream()
+        # One side stream per container for its size-chain walk (a single latency-bound wavefront, ~30-45 ms for 65536
+        # hops): the walks of different containers overlap each other and the compression of the following containers.
+        # Their descriptors live on the device and take the stream length from the compressor's device-side result, so
+        # the host never waits inside the compress phase.
+        self.side_streams = [torch.cuda.Stream() for _ in container_ids]
         self.index_done = [torch.cuda.Event() for _ in container_ids]
+        self.descs = [shb.make_stream_descs([
+            dict(stream=self.streams[i], stream_len=0, block_offsets=self.boffs[i], result=self.results[i],
+                 total_len=self.n, block_size=BLOCK_SIZE, header_len=self.hdr, num_blocks=self.nb)])
+            for i in range(self.count)]
+        self.d_stream_lens = torch.zeros(self.count, dtype=torch.int64, device="cuda")
 
     def _timed(self, key, record, fn):
         if not record:
@@ -109,30 +118,26 @@ class Batch:
     def step(self, record=False):
         shb, torch = self.shb, self.torch
         main = torch.cuda.current_stream()
-        side = self.side_stream
-        keep = []
-        # ---- compress every container; the size-chain walk of container i (one wavefront, latency-bound)
-        #      runs on a side stream underneath the compression of container i+1 ----
+        # ---- compress every container; the size-chain walk of container i runs on its own side stream underneath
+        #      the compression of the containers after it ----
         for i, d_in in enumerate(self.inputs):
             self._timed("compress", record, lambda: shb.compress_blocks(d_in, self.n, self.ws))
             shb.compact(self.n, self.ws, self.streams[i])
-            self.stream_lens[i] = int(self.ws.stream_len.item())      # 8-byte D2H; the decoder needs the length
+            # device-side hand-over of the stream length (descriptor field at byte 8, and the list the host reads later)
+            self.descs[i][8:16].copy_(self.ws.stream_len.view(torch.uint8), non_blocking=True)
+            self.d_stream_lens[i:i + 1].copy_(self.ws.stream_len, non_blocking=True)
+            side = self.side_streams[i]
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                descs = shb.make_stream_descs([
-                    dict(stream=self.streams[i], stream_len=self.stream_lens[i], block_offsets=self.boffs[i],
-                         result=self.results[i], total_len=self.n, block_size=BLOCK_SIZE, header_len=self.hdr,
-                         num_blocks=self.nb)])
-                shb.index_streams(descs, 1)
+                shb.index_streams(self.descs[i], 1)
                 self.index_done[i].record(side)
-            keep.append(descs)
+        self.stream_lens = [int(v) for v in self.d_stream_lens.cpu().tolist()]   # the decoder's launch needs the lengths
         # ---- decompress each stream as soon as its index is ready ----
         for i in range(self.count):
             main.wait_event(self.index_done[i])
             self._timed("decompress", record,
                         lambda: shb.decompress_blocks(self.streams[i], self.stream_lens[i], self.boffs[i], self.n,
                                                       BLOCK_SIZE, self.out, self.status))
-        self._keep = keep
 
     def verify(self):
         """Outside the timed region: every container round-trips bit-exactly and every block decoded OK."""
