@@ -2048,6 +2048,82 @@ __device__ __forceinline__ void predecode(uint64_t w, uint32_t pos, uint32_t csz
 // kLdsWindow = false: the decoded block is written straight to its place in global memory and back-references
 //   are read from there (vector memory operations of one wavefront complete in issue order on gfx9-family
 //   hardware, so a load issued after a store to the same bytes observes it); no LDS, 32 waves/CU.
+// K2's element loop for the common elements, hand-scheduled for gfx950 (K2 is instruction-issue bound: 13.3e9 instructions
+// per 2 GiB container, ~40 per copy and ~35 per literal in the compiler's version of this loop; here 27 and 20).
+// Handles, for elements that start in the current 64-byte window: a literal whose payload lies inside the window
+// (`v_readlane` the pre-decoded header, one exec-masked byte store from the window registers) and a non-overlapping copy of
+// up to 63 bytes (one exec-masked byte load + store; same-wave vector memory operations complete in order, so a later load
+// sees an earlier store).  Returns with cp/op advanced as soon as it meets anything else -- an invalid or truncated element,
+// a literal that runs into the next window, an overlapping or 64-byte copy -- and the C++ loop takes that element.
+// The CPU emulator compiles an empty body: there the C++ loop does everything, which is also the specification.
+__device__ __forceinline__ void k2_fast_elements(uint32_t meta, uint32_t offv, uint32_t w0_lo, uint32_t lane, uint8_t* win,
+                                                 uint32_t g, uint32_t wend, uint32_t out_len, uint32_t& cp, uint32_t& op)
+{
+#ifndef SNAPPY_EMU
+    uint32_t s, m, len, t, hdr, x, off;
+    uint32_t va, vd;
+    asm volatile(
+        "1:\n"
+        "  s_cmp_ge_u32 %[cp], %[wend]\n"
+        "  s_cbranch_scc1 9f\n"
+        "  s_sub_u32 %[s], %[cp], %[g]\n"
+        "  v_readlane_b32 %[m], %[meta], %[s]\n"
+        "  s_cmp_eq_u32 %[m], 0\n"
+        "  s_cbranch_scc1 9f\n"                       // rejected by predecode
+        "  s_lshr_b32 %[len], %[m], 8\n"
+        "  s_add_u32 %[t], %[op], %[len]\n"
+        "  s_cmp_gt_u32 %[t], %[outlen]\n"
+        "  s_cbranch_scc1 9f\n"                       // would overrun the block's output
+        "  s_bfe_u32 %[hdr], %[m], 0x30002\n"
+        "  s_and_b32 %[x], %[m], 3\n"
+        "  s_cmp_eq_u32 %[x], 0\n"
+        "  s_cbranch_scc1 5f\n"
+        // ---- copy ----
+        "  v_readlane_b32 %[off], %[offv], %[s]\n"
+        "  s_sub_u32 %[x], %[off], 1\n"
+        "  s_cmp_ge_u32 %[x], %[op]\n"
+        "  s_cbranch_scc1 9f\n"                       // offset 0 or before the block start
+        "  s_cmp_lt_u32 %[off], %[len]\n"
+        "  s_cbranch_scc1 9f\n"                       // overlapping copy
+        "  s_cmp_gt_u32 %[len], 63\n"
+        "  s_cbranch_scc1 9f\n"
+        "  s_sub_u32 %[x], %[op], %[off]\n"
+        "  s_bfm_b64 exec, %[len], 0\n"
+        "  v_add_u32 %[va], %[x], %[lane]\n"
+        "  global_load_ubyte %[vd], %[va], %[win]\n"
+        "  v_add_u32 %[va], %[op], %[lane]\n"
+        "  s_add_u32 %[cp], %[cp], %[hdr]\n"
+        "  s_mov_b32 %[op], %[t]\n"
+        "  s_waitcnt vmcnt(0)\n"
+        "  global_store_byte %[va], %[vd], %[win]\n"
+        "  s_mov_b64 exec, -1\n"
+        "  s_branch 1b\n"
+        // ---- literal ----
+        "5:\n"
+        "  s_add_u32 %[x], %[s], %[hdr]\n"            // payload start, as a window lane
+        "  s_add_u32 %[m], %[x], %[len]\n"
+        "  s_cmp_gt_u32 %[m], 64\n"
+        "  s_cbranch_scc1 9f\n"                       // payload runs into the next granule
+        "  s_bfm_b64 exec, %[len], %[x]\n"            // len <= 60 here
+        "  s_sub_u32 %[m], %[op], %[x]\n"
+        "  v_add_u32 %[va], %[m], %[lane]\n"
+        "  global_store_byte %[va], %[w0], %[win]\n"
+        "  s_mov_b64 exec, -1\n"
+        "  s_add_u32 %[cp], %[cp], %[hdr]\n"
+        "  s_add_u32 %[cp], %[cp], %[len]\n"
+        "  s_mov_b32 %[op], %[t]\n"
+        "  s_branch 1b\n"
+        "9:\n"
+        : [cp] "+s"(cp), [op] "+s"(op), [s] "=&s"(s), [m] "=&s"(m), [len] "=&s"(len), [t] "=&s"(t), [hdr] "=&s"(hdr), [x] "=&s"(x),
+          [off] "=&s"(off), [va] "=&v"(va), [vd] "=&v"(vd)
+        : [meta] "v"(meta), [offv] "v"(offv), [w0] "v"(w0_lo), [lane] "v"(lane), [win] "s"(win), [g] "s"(g), [wend] "s"(wend),
+          [outlen] "s"(out_len)
+        : "scc", "memory");
+#else
+    (void)meta; (void)offv; (void)w0_lo; (void)lane; (void)win; (void)g; (void)wend; (void)out_len; (void)cp; (void)op;
+#endif
+}
+
 template <bool kLdsWindow>
 __global__ __launch_bounds__(64) void decompress_blocks_kernel(const uint8_t* __restrict__ stream, uint64_t stream_len,
                                                                const uint64_t* __restrict__ block_offsets,
@@ -2105,6 +2181,10 @@ __global__ __launch_bounds__(64) void decompress_blocks_kernel(const uint8_t* __
             const uint32_t wend = (csz < g + 64) ? csz : g + 64;
 
             while (cp < wend) {                                          // :232, elements that start in this window
+                if (!kLdsWindow) {                                       // the common elements, hand-scheduled
+                    k2_fast_elements(meta, offv, (uint32_t)w0, lane, win, g, wend, out_len, cp, op);
+                    if (cp >= wend) break;
+                }
                 const uint32_t s = cp - g;                               // lane that holds this element's tag
                 const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)meta, (int)s);
                 const uint32_t type = m & 3, hdr = (m >> 2) & 7, len = m >> 8;
