@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Cycle-counter phase profile of K2 (needs an instrumented libsnappy_hip_prof.so built from a scratch copy of csrc with
-s_memtime probes; not part of the product).  Usage: python tools/prof_phases_k2.py MiB"""
+"""Cycle-counter phase profile of K2 (needs `python tools/make_probe_build.py --k2` first: an instrumented
+libsnappy_hip_prof.so with s_memtime probes; not part of the product).  Usage: python tools/prof_phases_k2.py MiB"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "pim-compression_amd"), os.path.join(ROOT, "tests")):
@@ -29,8 +29,8 @@ e0.record(); shb.decompress_blocks(d_stream, slen, boff, n, 32768, out, status);
 o = (ctypes.c_ulonglong * 32)(); L.snappy_hip_debug_prof(o, 0)
 tot = max(o[0], 1)
 print(f"K2 {e0.elapsed_time(e1):.2f} ms, blocks {o[1]}, cycles/block {tot/max(o[1],1):.0f}, ok={torch.equal(out[:n], d_in[:n])}")
-for name, t, c in (("window+predecode", o[2], o[3]), ("literal (window)", o[4], o[5]), ("copy", o[6], o[7]), ("long literal", o[9], o[10])):
+for name, t, c in (("window+predecode", o[2], o[3]), ("fast loop (asm)", o[11], o[3]), ("literal (C++ path)", o[4], o[5]), ("copy (C++ path)", o[6], o[7]), ("long literal", o[9], o[10])):
     print(f"   {name:18s} {100.0*t/tot:5.1f}%  n={c:11d}  {t/max(c,1):7.0f} cycles each")
 print(f"   overlapping copies {o[8]} of {o[7]}")
-rest = tot - o[2] - o[4] - o[6] - o[9]
+rest = tot - o[2] - o[4] - o[6] - o[9] - o[11]
 print(f"   rest {100.0*rest/tot:5.1f}%")
