@@ -159,6 +159,23 @@ int snappy_hip_compress_blocks(const uint8_t *d_in, uint64_t input_len, uint32_t
                                void *d_scratch, uint64_t scratch_bytes, void *stream);
 
 /*
+ * K1 over a batch of containers in ONE launch: the same per-block semantics as snappy_hip_compress_blocks for every
+ * item (its own input, slot array and size array; all with the same block_size and slot_stride), the persistent
+ * wavefronts drawing blocks of all containers from one counter, so the batch has one tail instead of one per container.
+ * This is the device-side form of the reference compressing many independent files, one `dpu_snappy -c` run each
+ * (snappy/dpu_snappy.c:160-172); items is a HOST array, empty containers are skipped, lists longer than 8 non-empty
+ * containers are issued as several launches on `stream`.
+ */
+struct snappy_hip_compress_item {
+    const void *d_input;        /* 16-byte aligned device pointer */
+    uint64_t input_len;         /* < 4 GiB */
+    void *d_slots;              /* num_blocks(input_len) * slot_stride bytes, 16-byte aligned */
+    void *d_block_bytes;        /* num_blocks(input_len) u32 */
+};
+int snappy_hip_compress_blocks_batch(const struct snappy_hip_compress_item *items, uint32_t count, uint32_t block_size,
+                                     uint32_t slot_stride, void *d_scratch, uint64_t scratch_bytes, void *stream);
+
+/*
  * Exclusive scan of d_block_bytes + gather of the slots into the contiguous framed stream
  * (header written too).  d_offsets: scratch/out, num_blocks+1 u64 (offset of each block in
  * d_stream; [num_blocks] = stream length, also stored to *d_stream_len if non-NULL).

@@ -175,27 +175,25 @@ hipError_t set_shard_device(int shard) { return hipSetDevice(shard % g_physical_
 // SNAPPY_HIP_K1_FORM[_LDS] = 1 selects the masked form (lane-mask resolution of the probes), 2 the bulk form
 // (per-segment table commit and emission); both need a look-ahead >= 16.
 template <uint32_t kAhead, int kForm>
-void launch_k1_global(uint32_t grid, hipStream_t st, const uint8_t* d_in, uint64_t input_len, uint32_t block_size, uint8_t* d_slots,
-                      uint32_t slot_stride, uint32_t* d_block_bytes, uint32_t nb, uint32_t* tables, uint32_t* counter)
+void launch_k1_global(uint32_t grid, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size, uint32_t slot_stride,
+                      uint32_t* tables, uint32_t* counter)
 {
-    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<kAhead, kForm>), dim3(grid), dim3(64), 0, st, d_in,
-                       input_len, block_size, d_slots, slot_stride, d_block_bytes, nb, tables, counter);
+    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<kAhead, kForm>), dim3(grid), dim3(64), 0, st, w, block_size,
+                       slot_stride, tables, counter);
 }
 // same, with the LDS "slot written" filter in front of the table (SNAPPY_HIP_K1_FILTER=1)
 template <uint32_t kAhead, int kForm>
-void launch_k1_global_filtered(uint32_t grid, hipStream_t st, const uint8_t* d_in, uint64_t input_len, uint32_t block_size,
-                               uint8_t* d_slots, uint32_t slot_stride, uint32_t* d_block_bytes, uint32_t nb, uint32_t* tables,
-                               uint32_t* counter)
+void launch_k1_global_filtered(uint32_t grid, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size,
+                               uint32_t slot_stride, uint32_t* tables, uint32_t* counter)
 {
-    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<kAhead, kForm, 1>), dim3(grid), dim3(64), 0, st, d_in,
-                       input_len, block_size, d_slots, slot_stride, d_block_bytes, nb, tables, counter);
+    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<kAhead, kForm, 1>), dim3(grid), dim3(64), 0, st, w,
+                       block_size, slot_stride, tables, counter);
 }
-inline void launch_k1_global_class_filtered(uint32_t grid, hipStream_t st, const uint8_t* d_in, uint64_t input_len,
-                                            uint32_t block_size, uint8_t* d_slots, uint32_t slot_stride, uint32_t* d_block_bytes,
-                                            uint32_t nb, uint32_t* tables, uint32_t* counter)
+inline void launch_k1_global_class_filtered(uint32_t grid, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size,
+                                            uint32_t slot_stride, uint32_t* tables, uint32_t* counter)
 {
-    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 2, 2>), dim3(grid), dim3(64), 0, st, d_in, input_len,
-                       block_size, d_slots, slot_stride, d_block_bytes, nb, tables, counter);
+    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 2, 2>), dim3(grid), dim3(64), 0, st, w, block_size,
+                       slot_stride, tables, counter);
 }
 #define SNAPPY_K1_DISPATCH_FILTERED(ahead, form, ...)                                   \
     do {                                                                                \
@@ -210,11 +208,11 @@ inline void launch_k1_global_class_filtered(uint32_t grid, hipStream_t st, const
         }                                                                               \
     } while (0)
 template <uint32_t kAhead, int kForm>
-void launch_k1_lds(uint32_t grid, uint32_t lds, hipStream_t st, const uint8_t* d_in, uint64_t input_len, uint32_t block_size,
-                   uint8_t* d_slots, uint32_t slot_stride, uint32_t* d_block_bytes, uint32_t nb, uint32_t* counter)
+void launch_k1_lds(uint32_t grid, uint32_t lds, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size,
+                   uint32_t slot_stride, uint32_t* counter)
 {
-    hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<kAhead, kForm>), dim3(grid), dim3(64), lds, st, d_in,
-                       input_len, block_size, d_slots, slot_stride, d_block_bytes, nb, counter);
+    hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<kAhead, kForm>), dim3(grid), dim3(64), lds, st, w, block_size,
+                       slot_stride, counter);
 }
 #define SNAPPY_K1_DISPATCH(fn, ahead, form, ...)                \
     do {                                                        \
@@ -313,17 +311,15 @@ uint64_t snappy_hip_compress_scratch_bytes(void)
     return 256 + (uint64_t)kGlobalTableWaves * snappy_hip::kMaxTableEntries * sizeof(uint32_t);
 }
 
-int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t block_size, uint8_t* d_slots,
-                               uint32_t slot_stride, uint32_t* d_block_bytes, void* d_scratch, uint64_t scratch_bytes,
-                               void* stream)
+// K1 over a batch of containers (count >= 1, every container non-empty and validated by the callers below)
+static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, uint32_t slot_stride, void* d_scratch,
+                           uint64_t scratch_bytes, void* stream)
 {
-    if (!block_size_ok(block_size)) return fail(SNAPPY_HIP_ERR_ARG, "block_size must be 1..65535");
-    if (input_len > 0xffffffffull) return fail(SNAPPY_HIP_ERR_ARG, "container length must fit uint32 (snappy_compress.c:461)");
-    if (slot_stride < snappy_hip_slot_stride(block_size)) return fail(SNAPPY_HIP_ERR_ARG, "slot_stride too small");
-    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_slots & 15)) return fail(SNAPPY_HIP_ERR_ARG, "d_in and d_slots must be 16-byte aligned");
-    const uint64_t nb = snappy_hip_num_blocks(input_len, block_size);
-    if (nb == 0) return SNAPPY_HIP_OK;
-    if (!d_in || !d_slots || !d_block_bytes) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
+    const uint64_t nb = w.first_block[w.count];
+    const uint8_t* d_in = w.in[0];                     // the single-container ablation kernels (variants 4, 5) use these
+    const uint64_t input_len = w.in_len[0];
+    uint8_t* d_slots = w.slots[0];
+    uint32_t* d_block_bytes = w.block_bytes[0];
     // SNAPPY_HIP_COMPRESS_VARIANT (ablations): 3 = windowed parse, hash tables in the caller's global scratch,
     // 32 waves/CU (default); 1 = LDS hash table, 4-5 waves/CU (also the path taken when no scratch is given);
     // 4 = lane-per-block SIMT experiment; 5 = four blocks per wavefront (16-lane groups).  SNAPPY_HIP_EXTRA_LDS adds dynamic LDS per workgroup (occupancy ablation).
@@ -331,6 +327,8 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
     if (variant == kVariantGlobalTable &&
         (!d_scratch || scratch_bytes < snappy_hip_compress_scratch_bytes() || ((uintptr_t)d_scratch & 255)))
         variant = kVariantLdsTable;   // no scratch: LDS-table kernel (still on the GPU)
+    if ((variant == kVariantGroup || variant == kVariantLanePerBlock) && w.count != 1)
+        return fail(SNAPPY_HIP_ERR_ARG, "the lane-per-block and group ablation kernels take one container per launch");
     const uint32_t lds = (uint32_t)env_int("SNAPPY_HIP_EXTRA_LDS", 0);
     const int k1_ahead = env_int("SNAPPY_HIP_K1_AHEAD", kDefaultK1Ahead);
     const int k1_ahead_lds = env_int("SNAPPY_HIP_K1_AHEAD_LDS", kDefaultK1AheadLds);
@@ -370,8 +368,7 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
         hipLaunchKernelGGL(snappy_hip::compress_blocks_lane_kernel, dim3((uint32_t)((nb * rep + 63) / 64)), block, 0, st, d_in,
                            input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, lane_tables, rep);
     } else if (variant == kVariantLdsTable) {
-        SNAPPY_K1_DISPATCH(launch_k1_lds, k1_ahead_lds, k1_masked_lds, (uint32_t)nb, lds, st, d_in, input_len, block_size, d_slots, slot_stride,
-                           d_block_bytes, (uint32_t)nb, (uint32_t*)nullptr);
+        SNAPPY_K1_DISPATCH(launch_k1_lds, k1_ahead_lds, k1_masked_lds, (uint32_t)nb, lds, st, w, block_size, slot_stride, (uint32_t*)nullptr);
     } else {
         // persistent grid, blocks handed out by an atomic counter kept in the first bytes of the scratch
         // Wave budget per CU (256 CUs, 32 wave slots, 160 KiB of LDS each): the LDS-table wavefronts hold a 32 KiB table
@@ -408,30 +405,86 @@ int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t
             hipEvent_t ev_begin = cr->ev_begin, ev_end = cr->ev_end;
             HIP_TRY(hipEventRecord(ev_begin, st));                     // after the counter memset and all prior work
             HIP_TRY(hipStreamWaitEvent(helper, ev_begin, 0));
-            SNAPPY_K1_DISPATCH(launch_k1_lds, k1_ahead_lds, k1_masked_lds, lds_waves, 0u, helper, d_in, input_len, block_size, d_slots, slot_stride,
-                               d_block_bytes, (uint32_t)nb, counter);
+            SNAPPY_K1_DISPATCH(launch_k1_lds, k1_ahead_lds, k1_masked_lds, lds_waves, 0u, helper, w, block_size, slot_stride, counter);
             HIP_TRY(hipEventRecord(ev_end, helper));
             if (k1_filter == 2)
-                launch_k1_global_class_filtered(g, st, d_in, input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);
+                launch_k1_global_class_filtered(g, st, w, block_size, slot_stride, tables, counter);
             else if (k1_filter)
-                SNAPPY_K1_DISPATCH_FILTERED(k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride,
-                                            d_block_bytes, (uint32_t)nb, tables, counter);
+                SNAPPY_K1_DISPATCH_FILTERED(k1_ahead, k1_masked, g, st, w, block_size, slot_stride, tables, counter);
             else
-                SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride,
-                                   d_block_bytes, (uint32_t)nb, tables, counter);
+                SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, w, block_size, slot_stride, tables, counter);
             HIP_TRY(hipStreamWaitEvent(st, ev_end, 0));                // the caller's stream resumes when both are done
         } else {
             if (k1_filter == 2)
-                launch_k1_global_class_filtered(g, st, d_in, input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, tables, counter);
+                launch_k1_global_class_filtered(g, st, w, block_size, slot_stride, tables, counter);
             else if (k1_filter)
-                SNAPPY_K1_DISPATCH_FILTERED(k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride,
-                                            d_block_bytes, (uint32_t)nb, tables, counter);
+                SNAPPY_K1_DISPATCH_FILTERED(k1_ahead, k1_masked, g, st, w, block_size, slot_stride, tables, counter);
             else
-                SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, d_in, input_len, block_size, d_slots, slot_stride,
-                                   d_block_bytes, (uint32_t)nb, tables, counter);
+                SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, w, block_size, slot_stride, tables, counter);
         }
     }
     HIP_TRY(hipGetLastError());
+    return SNAPPY_HIP_OK;
+}
+
+static int check_container(const void* d_in, uint64_t input_len, uint32_t block_size, const void* d_slots, uint32_t slot_stride,
+                           const void* d_block_bytes)
+{
+    if (!block_size_ok(block_size)) return fail(SNAPPY_HIP_ERR_ARG, "block_size must be 1..65535");
+    if (input_len > 0xffffffffull) return fail(SNAPPY_HIP_ERR_ARG, "container length must fit uint32 (snappy_compress.c:461)");
+    if (slot_stride < snappy_hip_slot_stride(block_size)) return fail(SNAPPY_HIP_ERR_ARG, "slot_stride too small");
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_slots & 15)) return fail(SNAPPY_HIP_ERR_ARG, "d_in and d_slots must be 16-byte aligned");
+    if (input_len && (!d_in || !d_slots || !d_block_bytes)) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
+    return SNAPPY_HIP_OK;
+}
+
+int snappy_hip_compress_blocks(const uint8_t* d_in, uint64_t input_len, uint32_t block_size, uint8_t* d_slots,
+                               uint32_t slot_stride, uint32_t* d_block_bytes, void* d_scratch, uint64_t scratch_bytes,
+                               void* stream)
+{
+    if (int rc = check_container(d_in, input_len, block_size, d_slots, slot_stride, d_block_bytes)) return rc;
+    const uint64_t nb = snappy_hip_num_blocks(input_len, block_size);
+    if (nb == 0) return SNAPPY_HIP_OK;
+    snappy_hip::K1Batch w{};
+    w.count = 1;
+    w.first_block[0] = 0;
+    w.first_block[1] = (uint32_t)nb;
+    w.in[0] = d_in;
+    w.in_len[0] = input_len;
+    w.slots[0] = d_slots;
+    w.block_bytes[0] = d_block_bytes;
+    return launch_compress(w, block_size, slot_stride, d_scratch, scratch_bytes, stream);
+}
+
+int snappy_hip_compress_blocks_batch(const struct snappy_hip_compress_item* items, uint32_t count, uint32_t block_size,
+                                     uint32_t slot_stride, void* d_scratch, uint64_t scratch_bytes, void* stream)
+{
+    if (!items && count) return fail(SNAPPY_HIP_ERR_ARG, "null item array");
+    // empty containers are skipped; a launch takes at most kMaxBatch non-empty ones, so longer lists go out in groups
+    uint32_t i = 0;
+    while (i < count) {
+        snappy_hip::K1Batch w{};
+        uint64_t blocks = 0;
+        while (i < count && w.count < snappy_hip::kMaxBatch) {
+            const snappy_hip_compress_item& it = items[i];
+            if (int rc = check_container(it.d_input, it.input_len, block_size, it.d_slots, slot_stride, it.d_block_bytes)) return rc;
+            const uint64_t nb = snappy_hip_num_blocks(it.input_len, block_size);
+            if (nb) {
+                if (blocks + nb > 0xffffffffull) break;
+                w.first_block[w.count] = (uint32_t)blocks;
+                w.in[w.count] = static_cast<const uint8_t*>(it.d_input);
+                w.in_len[w.count] = it.input_len;
+                w.slots[w.count] = static_cast<uint8_t*>(it.d_slots);
+                w.block_bytes[w.count] = static_cast<uint32_t*>(it.d_block_bytes);
+                blocks += nb;
+                ++w.count;
+            }
+            ++i;
+        }
+        w.first_block[w.count] = (uint32_t)blocks;
+        if (w.count)
+            if (int rc = launch_compress(w, block_size, slot_stride, d_scratch, scratch_bytes, stream)) return rc;
+    }
     return SNAPPY_HIP_OK;
 }
 

@@ -1383,16 +1383,33 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
     __builtin_amdgcn_wave_barrier();
 }
 
+// One K1 launch can serve several containers (independent inputs with their own slot / size arrays): the persistent
+// wavefronts draw GLOBAL block numbers and map them to (container, block) here, so a batch has one tail instead of one per
+// container.  Passed by value; the kernel argument segment is indexed with scalar loads.
+constexpr uint32_t kMaxBatch = 8;
+struct K1Batch {
+    uint32_t count;
+    uint32_t first_block[kMaxBatch + 1];   // first_block[count] = total number of blocks
+    const uint8_t* in[kMaxBatch];
+    uint64_t in_len[kMaxBatch];
+    uint8_t* slots[kMaxBatch];
+    uint32_t* block_bytes[kMaxBatch];
+};
+__device__ __forceinline__ uint32_t batch_container_of(const K1Batch& w, uint32_t b)
+{
+    uint32_t c = 0;
+    while (c + 1 < w.count && b >= w.first_block[c + 1]) ++c;
+    return c;
+}
+
 // next_block == nullptr: static grid-stride assignment; otherwise blocks are drawn from the shared atomic counter,
 // which lets this kernel run CONCURRENTLY with compress_blocks_global_table_kernel on the same container (the
 // LDS-table waves fill 5 wave slots per CU with low-latency tables, the global-table waves the other 27).
 template <uint32_t kAhead, int kForm = 0>
-__global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
-                                                                       uint32_t block_size, uint8_t* __restrict__ slots,
-                                                                       uint32_t slot_stride,
-                                                                       uint32_t* __restrict__ block_bytes, uint32_t num_blocks,
+__global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const K1Batch w, uint32_t block_size, uint32_t slot_stride,
                                                                        uint32_t* next_block)
 {
+    const uint32_t num_blocks = w.first_block[w.count];
     __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTableEntries];
     __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kForm ? kDupSlots : 16];
     const uint32_t lane = threadIdx.x;
@@ -1409,20 +1426,23 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uin
             b = uni(drawn);
         }
         if (b >= num_blocks) break;
-        const uint64_t start = (uint64_t)b * block_size;
+        const uint32_t c = batch_container_of(w, b);
+        const uint32_t lb = b - w.first_block[c];
+        const uint8_t* __restrict__ in = w.in[c];
+        const uint64_t in_len = w.in_len[c];
+        uint8_t* __restrict__ slot = w.slots[c] + (uint64_t)lb * slot_stride;
+        uint32_t* __restrict__ bytes_out = w.block_bytes[c] + lb;
+        const uint64_t start = (uint64_t)lb * block_size;
         const uint64_t left = in_len - start;
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
-        const uint8_t* __restrict__ blk = in + start;
-        (void)blk;
         if (kForm == 2)
-            compress_one_block_bulk<LdsTable, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, LdsTable{table},
-                                                      lane, block_bytes + b, (lds_bytes_t)dup_scratch);
+            compress_one_block_bulk<LdsTable, kAhead>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out,
+                                                      (lds_bytes_t)dup_scratch);
         else if (kForm == 1)
-            compress_one_block_masked<LdsTable, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, LdsTable{table},
-                                                        lane, block_bytes + b, (lds_bytes_t)dup_scratch);
+            compress_one_block_masked<LdsTable, kAhead>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out,
+                                                        (lds_bytes_t)dup_scratch);
         else
-            compress_one_block_windowed<LdsTable, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride,
-                                                          LdsTable{table}, lane, block_bytes + b);
+            compress_one_block_windowed<LdsTable, kAhead>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out);
         if (next_block && lane == 0) atomicAdd(next_block + 4, 1u);   // statistics: blocks taken by the LDS-table form
         __syncthreads();
         b += gridDim.x;
@@ -1430,13 +1450,10 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const uin
 }
 
 template <uint32_t kAhead, int kForm = 0, int kFilter = 0>
-__global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
-                                                                          uint32_t block_size, uint8_t* __restrict__ slots,
-                                                                          uint32_t slot_stride,
-                                                                          uint32_t* __restrict__ block_bytes,
-                                                                          uint32_t num_blocks, uint32_t* table_scratch,
-                                                                          uint32_t* next_block)
+__global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const K1Batch w, uint32_t block_size, uint32_t slot_stride,
+                                                                          uint32_t* table_scratch, uint32_t* next_block)
 {
+    const uint32_t num_blocks = w.first_block[w.count];
     __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kForm ? kDupSlots : 16];
     __shared__ __attribute__((aligned(16))) uint32_t slot_state[kFilter == 2 ? kMaxTableEntries / 16 : (kFilter ? kMaxTableEntries / 32 : 4)];
     const uint32_t lane = threadIdx.x;
@@ -1457,18 +1474,21 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
         if (lane == 0) b = atomicAdd(next_block, 1u);
         b = uni(b);
         if (b >= num_blocks) break;
-        const uint64_t start = (uint64_t)b * block_size;
+        const uint32_t c = batch_container_of(w, b);
+        const uint32_t lb = b - w.first_block[c];
+        const uint8_t* __restrict__ in = w.in[c];
+        const uint64_t in_len = w.in_len[c];
+        uint8_t* __restrict__ slot = w.slots[c] + (uint64_t)lb * slot_stride;
+        uint32_t* __restrict__ bytes_out = w.block_bytes[c] + lb;
+        const uint64_t start = (uint64_t)lb * block_size;
         const uint64_t left = in_len - start;
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
         if (kForm == 2)
-            compress_one_block_bulk<Table, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, table,
-                                                               lane, block_bytes + b, (lds_bytes_t)dup_scratch);
+            compress_one_block_bulk<Table, kAhead>(in, start, in_len, n, slot, table, lane, bytes_out, (lds_bytes_t)dup_scratch);
         else if (kForm == 1)
-            compress_one_block_masked<Table, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride, table,
-                                                                 lane, block_bytes + b, (lds_bytes_t)dup_scratch);
+            compress_one_block_masked<Table, kAhead>(in, start, in_len, n, slot, table, lane, bytes_out, (lds_bytes_t)dup_scratch);
         else
-            compress_one_block_windowed<Table, kAhead>(in, start, in_len, n, slots + (uint64_t)b * slot_stride,
-                                                                   table, lane, block_bytes + b);
+            compress_one_block_windowed<Table, kAhead>(in, start, in_len, n, slot, table, lane, bytes_out);
     }
 }
 

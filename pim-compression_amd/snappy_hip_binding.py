@@ -70,6 +70,8 @@ def lib():
         L.snappy_hip_parse_header.argtypes = [vp, u64, ctypes.POINTER(u32), ctypes.POINTER(u32)]
         L.snappy_hip_compress_blocks.restype = ctypes.c_int
         L.snappy_hip_compress_blocks.argtypes = [vp, u64, u32, vp, u32, vp, vp, u64, vp]
+        L.snappy_hip_compress_blocks_batch.restype = ctypes.c_int
+        L.snappy_hip_compress_blocks_batch.argtypes = [vp, u32, u32, u32, vp, u64, vp]
         L.snappy_hip_compress_scratch_bytes.restype = u64
         L.snappy_hip_compact.restype = ctypes.c_int
         L.snappy_hip_compact.argtypes = [vp, u32, vp, u64, u32, vp, vp, vp, vp]
@@ -166,6 +168,27 @@ def compress_blocks(d_in, n, ws):
     _check(lib().snappy_hip_compress_blocks(d_in.data_ptr(), n, ws.block_size, ws.slots.data_ptr(), ws.stride,
                                             ws.block_bytes.data_ptr(), ws.scratch_ptr, ws.scratch_bytes,
                                             _stream_handle(torch)), "snappy_hip_compress_blocks")
+
+
+class _CompressItem(ctypes.Structure):          # struct snappy_hip_compress_item
+    _fields_ = [("d_input", ctypes.c_void_p), ("input_len", ctypes.c_uint64), ("d_slots", ctypes.c_void_p),
+                ("d_block_bytes", ctypes.c_void_p)]
+
+
+def compress_blocks_batch(jobs, scratch_ws=None):
+    """K1 over several containers in one launch.  jobs: list of (d_in, n, ws); every ws has its own slots / block_bytes,
+    the scratch of `scratch_ws` (default: the first job's) is the launch's hash-table workspace."""
+    import torch
+    if not jobs:
+        return
+    sw = scratch_ws or jobs[0][2]
+    items = (_CompressItem * len(jobs))()
+    for k, (d_in, n, ws) in enumerate(jobs):
+        assert ws.block_size == sw.block_size and ws.stride == sw.stride
+        items[k] = _CompressItem(d_in.data_ptr(), n, ws.slots.data_ptr(), ws.block_bytes.data_ptr())
+    _check(lib().snappy_hip_compress_blocks_batch(ctypes.cast(items, ctypes.c_void_p), len(jobs), sw.block_size, sw.stride,
+                                                  sw.scratch_ptr, sw.scratch_bytes, _stream_handle(torch)),
+           "snappy_hip_compress_blocks_batch")
 
 
 def compact(n, ws, d_stream):

@@ -221,6 +221,14 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
     std::vector<uint8_t> inbuf(n + 64, 0x55);
     if (n) memcpy(inbuf.data(), in, n);
     std::vector<uint16_t> lane_tables(variant == 4 ? (size_t)nb * 16384 : 1);
+    snappy_hip::K1Batch w{};
+    w.count = 1;
+    w.first_block[0] = 0;
+    w.first_block[1] = nb;
+    w.in[0] = inbuf.data();
+    w.in_len[0] = n;
+    w.slots[0] = slots.data();
+    w.block_bytes[0] = bytes.data();
     if (nb && variant == 3) {
         // persistent kernel: a few workgroups pull blocks from the shared counter
         const uint32_t grid = nb < 3 ? nb : 3;
@@ -229,27 +237,27 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
         emu::launch(grid, 64, [&] {
             if (filter_kind == 2) {
                 EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 2, 2>(
-                                                   inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter)));
+                                                   w, block_size, stride, tables.data(), &counter)));
             } else if (filtered) {
                 if (form == 2) {
                     EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 2, 1>(
-                                                       inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter)));
+                                                       w, block_size, stride, tables.data(), &counter)));
                 } else if (form == 1) {
                     EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 1, 1>(
-                                                       inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter)));
+                                                       w, block_size, stride, tables.data(), &counter)));
                 } else {
                     EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<kA, 0, 1>(
-                                                       inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter)));
+                                                       w, block_size, stride, tables.data(), &counter)));
                 }
             } else if (form == 2) {
                 EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 2>(
-                                                   inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter)));
+                                                   w, block_size, stride, tables.data(), &counter)));
             } else if (masked) {
                 EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 1>(
-                                                   inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter)));
+                                                   w, block_size, stride, tables.data(), &counter)));
             } else {
                 EMU_AHEAD_DISPATCH(ahead_code, snappy_hip::compress_blocks_global_table_kernel<kA>(
-                                                   inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, tables.data(), &counter));
+                                                   w, block_size, stride, tables.data(), &counter));
             }
         });
     } else if (nb && variant == 5) {
@@ -268,13 +276,13 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
             } else
                 if (form == 2) {
                     EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_lds_table_kernel<(kA ? kA : 8), 2>(
-                                                       inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, nullptr)));
+                                                       w, block_size, stride, nullptr)));
                 } else if (masked) {
                     EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_lds_table_kernel<(kA ? kA : 8), 1>(
-                                                       inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, nullptr)));
+                                                       w, block_size, stride, nullptr)));
                 } else {
                     EMU_AHEAD_DISPATCH(ahead_code, snappy_hip::compress_blocks_lds_table_kernel<kA>(
-                                                       inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, nullptr));
+                                                       w, block_size, stride, nullptr));
                 }
         });
     emu::launch(1, 1024, [&] {

@@ -4,6 +4,8 @@ decompress."""
 import hashlib
 
 import numpy as np
+import os
+
 import pytest
 
 import datagen
@@ -246,6 +248,37 @@ def test_kernel_variants_bit_exact(shb, env, monkeypatch):
             assert gpu_compress(shb, data, bs) == ref, (env, bs)
             st, out = gpu_decompress(shb, ref)
             assert st == 0 and out == data, (env, bs)
+
+
+def test_batched_launch_matches_per_container_oracle(shb):
+    """snappy_hip_compress_blocks_batch: several containers (ragged, one empty, one tiny) in one launch, each stream == oracle."""
+    import torch
+    text = golden_bytes("plrabn12.txt")
+    datas = [golden_bytes("world192.txt"), datagen.text_random_interleave(text, 300_000), b"", datagen.records(77_777),
+             b"abc", datagen.lz_structured(200_000, 5), golden_bytes("coding.txt"),
+             datagen.zeros(131072), datagen.random_bytes(65_537), datagen.periodic(50_000, 9), datagen.records(12_345)]
+    for bs in (32768, 4097):
+        jobs, keep = [], []
+        for data in datas:
+            d = to_dev(data) if len(data) else torch.empty(16, dtype=torch.uint8, device="cuda")
+            ws = shb.CompressWorkspace(max(len(data), 1), bs)
+            jobs.append((d, len(data), ws))
+            keep.append(d)
+        for env in ({}, {"SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1", "SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11"}):
+            for k, v in env.items():
+                os.environ[k] = v
+            try:
+                shb.compress_blocks_batch(jobs)
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+            for data, (d, n, ws) in zip(datas, jobs):
+                if n == 0:
+                    continue
+                out = torch.empty(ws.stream_capacity(n) + 16, dtype=torch.uint8, device="cuda")
+                shb.compact(n, ws, out)
+                slen = int(ws.stream_len.item())
+                assert bytes(out[:slen].cpu().numpy()) == oracle.compress(data, bs, threads=4), (bs, n)
 
 
 def test_compress_without_scratch_uses_lds_table_kernel(shb):
