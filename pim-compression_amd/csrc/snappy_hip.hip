@@ -101,6 +101,7 @@ constexpr int kDefaultK1Ahead = 64;     // look-ahead of the global-table form (
 constexpr int kDefaultK1AheadLds = 64;  // look-ahead of the LDS-table form
 constexpr int kDefaultK1Form = 2;       // bulk form for the global-table kernel
 constexpr int kDefaultK1Filter = 1;     // with the LDS slot filter
+constexpr int kDefaultLdsHeadStart = 6; // ~20 us for the LDS-table workgroups to be placed before the global-table kernel starts
 constexpr int kDefaultK1FormLds = 2;    // bulk form for the LDS-table kernel
 constexpr int kDefaultLdsWaves = 768;   // 3 LDS-table wavefronts per CU (3 x 33 KiB) beside 20 global-table ones (3 KiB each: filter + duplicate test)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
@@ -407,6 +408,8 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
             HIP_TRY(hipStreamWaitEvent(helper, ev_begin, 0));
             SNAPPY_K1_DISPATCH(launch_k1_lds, k1_ahead_lds, k1_masked_lds, lds_waves, 0u, helper, w, block_size, slot_stride, counter);
             HIP_TRY(hipEventRecord(ev_end, helper));
+            if (const int head_start = env_int("SNAPPY_HIP_LDS_HEAD_START", kDefaultLdsHeadStart))   // x 3.4 us
+                hipLaunchKernelGGL(snappy_hip::delay_kernel, dim3(1), dim3(64), 0, st, (uint32_t)head_start);
             if (k1_filter == 2)
                 launch_k1_global_class_filtered(g, st, w, block_size, slot_stride, tables, counter);
             else if (k1_filter)
