@@ -808,15 +808,21 @@ struct MaskedWindowState {
     __device__ __forceinline__ void gather(const Table& table, const CursorWindow& win, lds_bytes_t scratch, uint32_t r,
                                            uint32_t span, uint32_t lane, uint32_t block_len = 0)
     {
-        if (!dup_valid) {
+        const uint32_t e = (r + span < kWave) ? r + span : kWave;
+        if (!kWithDup && !dup_valid) {                 // the gather mask needs DUP first
             dup = dup_slot_lanes(scratch, win.h0, lane);
             dup_valid = true;
         }
-        const uint32_t e = (r + span < kWave) ? r + span : kWave;
         const unsigned long long gm = kWithDup ? lane_range(r, e - r) : (lane_range(r, e - r) & ~dup);
         const bool g = __builtin_amdgcn_inverse_ballot_w64(gm);
         const uint32_t mine_l = win.e0 | (win.base + lane);
         if (g) ent = table.load_lane(win.h0, mine_l);
+        if (kWithDup && !dup_valid) {                  // run the LDS duplicate test underneath the table loads
+            __builtin_amdgcn_sched_barrier(0);
+            dup = dup_slot_lanes(scratch, win.h0, lane);
+            dup_valid = true;
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const bool worth = g && !Table::certain_miss(ent, mine_l);
         uint32_t k0 = 0, k1 = 0, k2 = 0;
         const bool deep = kDeep && worth && (win.base + lane + 28u <= block_len);   // candidate < position, so it has 28 too
