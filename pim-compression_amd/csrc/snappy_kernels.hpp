@@ -2079,7 +2079,11 @@ __device__ __forceinline__ void predecode(uint64_t w, uint32_t pos, uint32_t csz
     off = (type == 0) ? 0u : ((type == 1) ? c1_off : ((type == 2) ? (next4 & 0xffff) : next4));
     const uint32_t consumed = hdr + ((type == 0) ? olen : 0);
     const bool ok = (olen != 0) && (pos + consumed <= csz);
-    meta = ok ? (type | (hdr << 2) | (olen << 8)) : 0;
+    // classes for the hand-scheduled element loop (k2_fast_elements): bit 5 = a copy it may take (offset != 0, no overlap,
+    // <= 63 bytes), bit 6 = a literal whose payload lies inside this 64-byte granule; the offset-vs-output checks stay dynamic
+    const uint32_t fast_copy = (type != 0 && off != 0 && off >= olen && olen <= 63u) ? 32u : 0u;
+    const uint32_t fast_lit = (type == 0 && (pos & 63u) + consumed <= 64u) ? 64u : 0u;
+    meta = ok ? (type | (hdr << 2) | fast_copy | fast_lit | (olen << 8)) : 0;
 }
 
 // kLdsWindow = true : the decoded block is staged in LDS (block_size bytes, ~4 blocks/CU) and written out at the end;
@@ -2088,7 +2092,8 @@ __device__ __forceinline__ void predecode(uint64_t w, uint32_t pos, uint32_t csz
 //   are read from there (vector memory operations of one wavefront complete in issue order on gfx9-family
 //   hardware, so a load issued after a store to the same bytes observes it); no LDS, 32 waves/CU.
 // K2's element loop for the common elements, hand-scheduled for gfx950 (K2 is instruction-issue bound: 13.3e9 instructions
-// per 2 GiB container, ~40 per copy and ~35 per literal in the compiler's version of this loop; here 27 and 20).
+// per 2 GiB container, ~40 per copy and ~35 per literal in the compiler's version of this loop; here 25 and 23, with the
+// static conditions folded into two class bits by predecode()).
 // Handles, for elements that start in the current 64-byte window: a literal whose payload lies inside the window
 // (`v_readlane` the pre-decoded header, one exec-masked byte store from the window registers) and a non-overlapping copy of
 // up to 63 bytes (one exec-masked byte load + store; same-wave vector memory operations complete in order, so a later load
@@ -2107,25 +2112,36 @@ __device__ __forceinline__ void k2_fast_elements(uint32_t meta, uint32_t offv, u
         "  s_cbranch_scc1 9f\n"
         "  s_sub_u32 %[s], %[cp], %[g]\n"
         "  v_readlane_b32 %[m], %[meta], %[s]\n"
-        "  s_cmp_eq_u32 %[m], 0\n"
-        "  s_cbranch_scc1 9f\n"                       // rejected by predecode
+        "  s_bitcmp1_b32 %[m], 5\n"
+        "  s_cbranch_scc1 3f\n"
+        "  s_bitcmp1_b32 %[m], 6\n"
+        "  s_cbranch_scc0 9f\n"                       // neither class (or rejected by predecode: meta == 0)
+        // ---- literal inside the granule ----
         "  s_lshr_b32 %[len], %[m], 8\n"
         "  s_add_u32 %[t], %[op], %[len]\n"
         "  s_cmp_gt_u32 %[t], %[outlen]\n"
         "  s_cbranch_scc1 9f\n"                       // would overrun the block's output
         "  s_bfe_u32 %[hdr], %[m], 0x30002\n"
-        "  s_and_b32 %[x], %[m], 3\n"
-        "  s_cmp_eq_u32 %[x], 0\n"
-        "  s_cbranch_scc1 5f\n"
-        // ---- copy ----
-        "  v_readlane_b32 %[off], %[offv], %[s]\n"
-        "  s_sub_u32 %[x], %[off], 1\n"
-        "  s_cmp_ge_u32 %[x], %[op]\n"
-        "  s_cbranch_scc1 9f\n"                       // offset 0 or before the block start
-        "  s_cmp_lt_u32 %[off], %[len]\n"
-        "  s_cbranch_scc1 9f\n"                       // overlapping copy
-        "  s_cmp_gt_u32 %[len], 63\n"
+        "  s_add_u32 %[x], %[s], %[hdr]\n"            // payload start, as a window lane
+        "  s_bfm_b64 exec, %[len], %[x]\n"            // len <= 63 here
+        "  s_sub_u32 %[m], %[op], %[x]\n"
+        "  v_add_u32 %[va], %[m], %[lane]\n"
+        "  global_store_byte %[va], %[w0], %[win]\n"
+        "  s_mov_b64 exec, -1\n"
+        "  s_add_u32 %[cp], %[cp], %[hdr]\n"
+        "  s_add_u32 %[cp], %[cp], %[len]\n"
+        "  s_mov_b32 %[op], %[t]\n"
+        "  s_branch 1b\n"
+        // ---- copy without overlap, <= 63 bytes ----
+        "3:\n"
+        "  s_lshr_b32 %[len], %[m], 8\n"
+        "  s_add_u32 %[t], %[op], %[len]\n"
+        "  s_cmp_gt_u32 %[t], %[outlen]\n"
         "  s_cbranch_scc1 9f\n"
+        "  v_readlane_b32 %[off], %[offv], %[s]\n"
+        "  s_cmp_gt_u32 %[off], %[op]\n"
+        "  s_cbranch_scc1 9f\n"                       // reaches before the block start
+        "  s_bfe_u32 %[hdr], %[m], 0x30002\n"
         "  s_sub_u32 %[x], %[op], %[off]\n"
         "  s_bfm_b64 exec, %[len], 0\n"
         "  v_add_u32 %[va], %[x], %[lane]\n"
@@ -2136,21 +2152,6 @@ __device__ __forceinline__ void k2_fast_elements(uint32_t meta, uint32_t offv, u
         "  s_waitcnt vmcnt(0)\n"
         "  global_store_byte %[va], %[vd], %[win]\n"
         "  s_mov_b64 exec, -1\n"
-        "  s_branch 1b\n"
-        // ---- literal ----
-        "5:\n"
-        "  s_add_u32 %[x], %[s], %[hdr]\n"            // payload start, as a window lane
-        "  s_add_u32 %[m], %[x], %[len]\n"
-        "  s_cmp_gt_u32 %[m], 64\n"
-        "  s_cbranch_scc1 9f\n"                       // payload runs into the next granule
-        "  s_bfm_b64 exec, %[len], %[x]\n"            // len <= 60 here
-        "  s_sub_u32 %[m], %[op], %[x]\n"
-        "  v_add_u32 %[va], %[m], %[lane]\n"
-        "  global_store_byte %[va], %[w0], %[win]\n"
-        "  s_mov_b64 exec, -1\n"
-        "  s_add_u32 %[cp], %[cp], %[hdr]\n"
-        "  s_add_u32 %[cp], %[cp], %[len]\n"
-        "  s_mov_b32 %[op], %[t]\n"
         "  s_branch 1b\n"
         "9:\n"
         : [cp] "+s"(cp), [op] "+s"(op), [s] "=&s"(s), [m] "=&s"(m), [len] "=&s"(len), [t] "=&s"(t), [hdr] "=&s"(hdr), [x] "=&s"(x),
