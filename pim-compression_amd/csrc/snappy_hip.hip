@@ -541,7 +541,8 @@ int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, c
     if (variant == 0) lds_waves = (uint32_t)std::min<uint64_t>(nb, resident);
     else if (variant == 2 && nb >= (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096))
         lds_waves = (uint32_t)env_int("SNAPPY_HIP_K2_LDS_WAVES", lds_bytes > 32768 ? 512 : 1024);
-    const uint32_t glob_waves = (variant == 0) ? 0 : (uint32_t)std::min<uint64_t>(nb, resident - std::min(lds_waves, resident / 2));
+    const uint32_t k2_cap = (uint32_t)std::max(1, env_int("SNAPPY_HIP_K2_WAVES", (int)resident));   // fewer wavefronts leave slots for a co-running kernel
+    const uint32_t glob_waves = (variant == 0) ? 0 : (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nb, k2_cap), resident - std::min(lds_waves, resident / 2));
     if (lds_waves && glob_waves) {
         CoRunResources* cr = nullptr;
         if (int rc = corun_resources(&cr)) return rc;
