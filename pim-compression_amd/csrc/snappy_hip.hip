@@ -514,8 +514,10 @@ int snappy_hip_index_streams(const snappy_hip_stream_desc* d_descs, uint32_t cou
     static_assert(sizeof(snappy_hip_stream_desc) == sizeof(snappy_hip::StreamDesc), "descriptor layout");
     if (count == 0) return SNAPPY_HIP_OK;
     if (!d_descs) return fail(SNAPPY_HIP_ERR_ARG, "null descriptor array");
-    hipLaunchKernelGGL(snappy_hip::index_streams_kernel, dim3(count), dim3(64), 0, (hipStream_t)stream,
-                       reinterpret_cast<const snappy_hip::StreamDesc*>(d_descs), count);
+    // SNAPPY_HIP_INDEX_READERS=0: the walking wavefront alone, without the read-ahead workgroups on its XCD
+    const uint32_t group = env_int("SNAPPY_HIP_INDEX_READERS", 1) ? snappy_hip::kIndexGroup : 1u;
+    hipLaunchKernelGGL(snappy_hip::index_streams_kernel, dim3(count * group), dim3(64 * snappy_hip::kIndexWgWaves), 0,
+                       (hipStream_t)stream, reinterpret_cast<const snappy_hip::StreamDesc*>(d_descs), count, group);
     HIP_TRY(hipGetLastError());
     return SNAPPY_HIP_OK;
 }

@@ -1988,28 +1988,100 @@ struct StreamDesc {            // must match snappy_hip_stream_desc (include/sna
     uint32_t num_blocks;
 };
 
-__global__ __launch_bounds__(64) void index_streams_kernel(const StreamDesc* __restrict__ descs, uint32_t count)
+// The chain of u32 block sizes is serial by format: 65536 dependent hops for a 2 GiB container, 950 cycles per hop when the
+// size field comes from HBM, 200 when it is in L2 (tools/microbench/l2_warm_probe).  So each stream gets a GROUP of
+// workgroups on one XCD (workgroup i runs on XCD i mod 8): one walks -- wave 0 of the first -- and the others only read
+// ahead, streaming the compressed bytes up to kIndexAheadSupers x 32 KiB in front of the walker through that XCD's L2 (one
+// CU cannot stream fast enough: ~40 GB/s).  The walker publishes its position in result[0] (top bit = "running"); the
+// readers stop when it stores the final status there.  If the placement assumption does not hold the walk is merely as
+// slow as without readers.
+constexpr uint32_t kIndexGroup = 64;           // workgroups launched per stream; those on the stream's XCD take part
+constexpr uint32_t kIndexReaderWgs = 7;
+constexpr uint32_t kIndexWgWaves = 4;
+constexpr uint32_t kIndexReaders = kIndexReaderWgs * kIndexWgWaves;
+constexpr uint32_t kIndexSuper = 8 * 4096;     // one read-ahead step of a wave: 8 loads x 64 lanes x 64 bytes apart
+constexpr uint32_t kIndexAheadSupers = 64;     // stay at most 2 MiB in front of the walker
+constexpr uint32_t kIndexRunning = 0x80000000u;
+__global__ __launch_bounds__(64 * kIndexWgWaves) void index_streams_kernel(const StreamDesc* __restrict__ descs, uint32_t count,
+                                                                           uint32_t group)
 {
-    const uint32_t s = blockIdx.x;
+    // group == 1: one workgroup per stream, no readers (also what the CPU emulator runs)
+    const uint32_t s = blockIdx.x / group;
+    const uint32_t j = blockIdx.x % group;
     if (s >= count) return;
+    uint32_t role = 0;                          // 0 = walker, 1.. = reader workgroup
+    if (group > 1) {
+        if ((j & 7u) != (s & 7u)) return;       // not on this stream's XCD
+        role = j >> 3;
+        if (role > kIndexReaderWgs) return;
+    }
     const StreamDesc d = descs[s];
-    const uint32_t lane = threadIdx.x;
-    uint64_t at = d.header_len;
-    uint32_t status = kBlockOk;
-    uint32_t i = 0;
-    for (; i < d.num_blocks; ++i) {
-        if (at + 4 > d.stream_len) {
-            status = kBlockInvalid;
-            break;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    volatile uint32_t* ctl = reinterpret_cast<volatile uint32_t*>(d.result);
+    if (role == 0) {
+        if (wave != 0) return;
+        uint64_t at = d.header_len;
+        uint32_t status = kBlockOk;
+        uint32_t i = 0;
+        if (group > 1 && lane == 0) ctl[0] = kIndexRunning;
+        // offsets are collected in registers (lane i & 63 keeps hop i's) and stored 64 at a time, so that a hop is the
+        // dependent load and nothing else: a store per hop would put its acknowledgement on every hop's wait
+        uint64_t mine_off = 0;
+        for (; i < d.num_blocks; ++i) {
+            if (at + 4 > d.stream_len) {
+                status = kBlockInvalid;
+                break;
+            }
+            if (lane == (i & 63u)) mine_off = at;
+            if ((i & 63u) == 63u) {
+                d.block_offsets[(i & ~63u) + lane] = mine_off;
+                if (group > 1 && lane == 0) ctl[0] = kIndexRunning | (uint32_t)(at / kIndexSuper);
+            }
+            at += 4 + (uint64_t)uld32(d.stream + at);
         }
-        if (lane == 0) d.block_offsets[i] = at;
-        at += 4 + (uint64_t)uld32(d.stream + at);
+        if ((i & 63u) != 0 && lane < (i & 63u)) d.block_offsets[(i & ~63u) + lane] = mine_off;   // the last partial group
+        if (status == kBlockOk && at != d.stream_len) status = kBlockInvalid;
+        if (lane == 0) {
+            d.result[1] = i;
+            __threadfence();
+            ctl[0] = status;                    // also tells the readers to stop
+        }
+        return;
     }
-    if (status == kBlockOk && at != d.stream_len) status = kBlockInvalid;
-    if (lane == 0) {
-        d.result[0] = status;
-        d.result[1] = i;
+    // reader wave h of kIndexReaders takes the super-chunks c = h (mod kIndexReaders)
+    const uint32_t mine = (role - 1u) * kIndexWgWaves + wave;
+    // super-chunk c is read at byte offsets below (c + 1) * kIndexSuper: it must lie inside the stream entirely
+    const uint64_t whole = d.stream_len / kIndexSuper;
+    if (whole == 0) return;                     // a stream shorter than one super-chunk: nothing to read ahead
+    const uint32_t last = (uint32_t)(whole - 1u);
+    uint32_t c = mine;
+    uint32_t sink = 0;
+    bool seen_running = false;
+    uint32_t patience = 4096;                   // bounded wait for the walker to start (it may be scheduled later)
+    for (;;) {
+        const uint32_t w = uni(ctl[0]);
+        if (!(w & kIndexRunning)) {
+            if (seen_running || --patience == 0) break;
+            __builtin_amdgcn_s_sleep(16);
+            continue;
+        }
+        seen_running = true;
+        const uint32_t lo = w & ~kIndexRunning;
+        if (c < lo) c = lo + ((mine + kIndexReaders - (lo % kIndexReaders)) % kIndexReaders);   // catch up with the walker
+        if (c > last) break;                    // the tail of the stream: nothing more to warm
+        if (c <= lo + kIndexAheadSupers) {
+            const uint8_t* __restrict__ q = d.stream + (uint64_t)c * kIndexSuper + (uint64_t)lane * 64u;
+            const uint32_t v0 = ld32(q), v1 = ld32(q + 4096), v2 = ld32(q + 8192), v3 = ld32(q + 12288);
+            const uint32_t v4 = ld32(q + 16384), v5 = ld32(q + 20480), v6 = ld32(q + 24576), v7 = ld32(q + 28672);
+            sink ^= v0 ^ v1 ^ v2 ^ v3 ^ v4 ^ v5 ^ v6 ^ v7;
+            c += kIndexReaders;
+        } else {
+            __builtin_amdgcn_s_sleep(16);
+        }
     }
+    // keeps the loads alive: a condition the compiler cannot decide (a stream never has 2^32 - 1 blocks)
+    if (sink == 0x9e3779b9u && d.num_blocks == 0xffffffffu) d.block_offsets[0] = sink;
 }
 
 // ---------------------------------------------------------------------------

@@ -310,7 +310,7 @@ int emu_decompress_variant(const uint8_t* stream, uint64_t stream_len, uint32_t 
     std::vector<uint64_t> boff(nb, 0);
     uint32_t result[2] = {7, 7};
     snappy_hip::StreamDesc d{stream, stream_len, boff.data(), result, total_len, block_size, header_len, nb};
-    emu::launch(1, 64, [&] { snappy_hip::index_streams_kernel(&d, 1); });
+    emu::launch(1, 64, [&] { snappy_hip::index_streams_kernel(&d, 1, 1u); });
     if (result[0] != 0 || result[1] != nb) return 1;
     std::vector<uint32_t> status(nb, 9);
     uint32_t k2_counter = 0;

@@ -21,8 +21,8 @@ hdr = len(shb.write_header(n, 32768))
 boff = torch.zeros(nb, dtype=torch.int64, device="cuda"); res = torch.zeros(2, dtype=torch.int32, device="cuda")
 descs = shb.make_stream_descs([dict(stream=d_stream, stream_len=slen, block_offsets=boff, result=res, total_len=n, block_size=32768,
                                     header_len=hdr, num_blocks=nb)])
-for waves in sys.argv[2:] or ["1", "16"]:
-    os.environ["SNAPPY_HIP_INDEX_WAVES"] = waves
+for waves in sys.argv[2:] or ["0", "1"]:
+    os.environ["SNAPPY_HIP_INDEX_READERS"] = waves
     ts = []
     for _ in range(4):
         boff.zero_()
@@ -30,4 +30,4 @@ for waves in sys.argv[2:] or ["1", "16"]:
         e0.record(); shb.index_streams(descs, 1); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     ok = torch.equal(boff, ws.offsets[:nb]) and res.cpu().tolist() == [0, nb]
-    print(f"index waves {waves:>2s}: " + " ".join(f"{t:6.2f}" for t in ts) + f" ms   offsets_ok={ok}", flush=True)
+    print(f"index readers {waves:>2s}: " + " ".join(f"{t:6.2f}" for t in ts) + f" ms   offsets_ok={ok}", flush=True)
