@@ -11,8 +11,10 @@
 #include <string.h>
 #include <sys/time.h>
 
+#include <algorithm>
 #include <atomic>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -121,27 +123,60 @@ int next_work_counter(uint32_t** out, hipStream_t st)
     return 0;
 }
 
-// Helper stream + fork/join events for launches that co-run two kernels, one set per (host thread, device):
-// created on first use on that device and reused.  The events are timing-disabled; the helper stream is
-// non-blocking, so the only ordering is the explicit fork (ev_begin) and join (ev_end) around the caller's stream.
+// Helper stream + fork/join events for launches that co-run two kernels, one set per (host thread, device).  The
+// events are timing-disabled; the helper stream is non-blocking, so the only ordering is the explicit fork (ev_begin)
+// and join (ev_end) around the caller's stream.
 struct CoRunResources {
     hipStream_t helper = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 };
 
+// The sets live in a per-device pool; a host thread leases one per device on first use and hands it back when it ends
+// (the drop-in pair runs one short-lived thread per shard), so streams are created once per process, not per call.
+struct CoRunPool {
+    std::mutex m;
+    std::vector<CoRunResources*> idle[64];
+};
+CoRunPool& corun_pool()
+{
+    static CoRunPool* pool = new CoRunPool;     // never destroyed: threads may outlive static destruction order
+    return *pool;
+}
+struct CoRunLease {
+    CoRunResources* held[64] = {};
+    ~CoRunLease()
+    {
+        CoRunPool& pool = corun_pool();
+        std::lock_guard<std::mutex> lock(pool.m);
+        for (int d = 0; d < 64; ++d)
+            if (held[d]) pool.idle[d].push_back(held[d]);
+    }
+};
+
 int corun_resources(CoRunResources** out)
 {
-    static thread_local CoRunResources per_device[64];
+    static thread_local CoRunLease lease;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(SNAPPY_HIP_ERR_ARG, "device index out of range");
-    CoRunResources& r = per_device[dev];
-    if (!r.helper) {
-        HIP_TRY(hipStreamCreateWithFlags(&r.helper, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&r.ev_begin, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&r.ev_end, hipEventDisableTiming));
+    if (!lease.held[dev]) {
+        CoRunPool& pool = corun_pool();
+        {
+            std::lock_guard<std::mutex> lock(pool.m);
+            if (!pool.idle[dev].empty()) {
+                lease.held[dev] = pool.idle[dev].back();
+                pool.idle[dev].pop_back();
+            }
+        }
+        if (!lease.held[dev]) {
+            CoRunResources* r = new CoRunResources;
+            HIP_TRY(hipStreamCreateWithFlags(&r->helper, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&r->ev_begin, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&r->ev_end, hipEventDisableTiming));
+            lease.held[dev] = r;
+        }
     }
-    *out = &r;
+    *out = lease.held[dev];
     return 0;
 }
 
@@ -575,17 +610,113 @@ int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, c
 
 namespace {
 
+// One pipeline stage unit of the overlapped drop-in pair: a contiguous run of blocks of a shard whose copy-in, kernels
+// and copy-out overlap those of its neighbours.
+struct CompressChunk {
+    uint64_t first_block = 0, num_blocks = 0;   // relative to the shard
+    uint64_t in_off = 0, in_len = 0;            // relative to the shard's input slice
+    uint8_t* d_stream = nullptr;                // this chunk's own framed stream (local header + blocks)
+    uint64_t *d_offsets = nullptr, *d_stream_len = nullptr;
+    uint32_t local_hdr = 0;
+    uint64_t stream_len = 0, out_off = 0;
+    hipEvent_t ev_in = nullptr, ev_k1 = nullptr, ev_run = nullptr;
+};
+
+struct DecompressChunk {
+    uint64_t first_block = 0, num_blocks = 0;   // relative to the shard
+    uint64_t in_off = 0, in_len = 0;            // relative to the shard's slice of the stream
+    uint64_t out_off = 0, out_len = 0;          // relative to the shard's slice of the output
+    hipEvent_t ev_in = nullptr, ev_run = nullptr;
+};
+
+// The compress pipeline keeps six streams busy at once (copy-in, two K1 launches, the LDS-table helper, framing,
+// copy-out).  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on
+// one queue run in enqueue order: measured here, the copy-in of chunk k+1 then waits for the K1 launch of chunk k and the
+// pipeline degenerates to the phased form (38 instead of 52 GB/s on a 3 GiB input).  So the library asks for 8 queues
+// when it is loaded, unless the variable is already set; a process that initialised HIP earlier keeps its setting and
+// loses only the overlap, never bytes.
+__attribute__((constructor)) void ask_for_hardware_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
+// Streams of one shard's pipeline.  Creating a stream costs milliseconds (a hardware queue each), so the sets are made
+// once per process and shard index and kept: a long-lived caller pays for them in its first call only.
+struct PipelineStreams {
+    hipStream_t in = nullptr, run = nullptr, run2 = nullptr, post = nullptr, out = nullptr;
+    hipEvent_t start = nullptr;
+    uint64_t* h_len = nullptr;          // page-locked scratch: stream length per chunk / block offsets
+    size_t h_len_count = 0;
+};
+
+int pipeline_streams(int shard, size_t chunks, PipelineStreams** out)
+{
+    static PipelineStreams per_shard[64];
+    if (shard < 0 || shard >= 64) return fail(SNAPPY_HIP_ERR_ARG, "shard index out of range");
+    PipelineStreams& p = per_shard[shard];                // shard g is only ever touched by the host thread driving shard g
+    if (!p.in) {
+        HIP_TRY(hipStreamCreateWithFlags(&p.in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&p.run, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&p.run2, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&p.post, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&p.out, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&p.start));
+        // a stream gets its hardware queue at first use: use each one now, in the load phase, not under the first chunk
+        uint32_t* c = nullptr;
+        for (hipStream_t st : {p.in, p.run, p.run2, p.post, p.out})
+            if (int rc = next_work_counter(&c, st)) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    if (chunks > p.h_len_count) {
+        if (p.h_len) (void)hipHostFree(p.h_len);
+        p.h_len = nullptr;
+        p.h_len_count = 0;
+        const size_t want = std::max<size_t>(chunks, 64);
+        HIP_TRY(hipHostMalloc((void**)&p.h_len, want * sizeof(uint64_t), hipHostMallocDefault));
+        p.h_len_count = want;
+    }
+    *out = &p;
+    return 0;
+}
+
+// SNAPPY_HIP_PIPELINE_BLOCKS: blocks per pipeline chunk of the drop-in pair (0 = strictly phased copy-in / run /
+// copy-out, the reference's own order).  Default: 4096 blocks -- a K1 launch of one block per resident wavefront, and
+// 128 MiB per copy -- shrinking to a quarter of the shard (not below 2048) so that a 256 MiB file still overlaps.
+uint64_t pipeline_chunk_blocks(uint64_t shard_blocks)
+{
+    const char* v = getenv("SNAPPY_HIP_PIPELINE_BLOCKS");
+    if (v && *v) return atoi(v) > 0 ? (uint64_t)atoi(v) : 0;
+    const uint64_t quarter = ((shard_blocks + 3) / 4 + 15) & ~15ull;
+    return std::min<uint64_t>(4096, std::max<uint64_t>(2048, quarter));
+}
+
+// split `nb` blocks into equal chunks of at most `chunk` blocks, each a multiple of 16 blocks (keeps every chunk's
+// input slice 16-byte aligned whatever the block size)
+struct BlockRange {
+    uint64_t first, second;
+};
+void split_blocks(uint64_t nb, uint64_t chunk, std::vector<BlockRange>& v)
+{
+    v.clear();
+    if (!nb) return;
+    const uint64_t parts = (nb + chunk - 1) / chunk;
+    uint64_t per = (nb + parts - 1) / parts;
+    per = (per + 15) & ~15ull;
+    for (uint64_t b = 0; b < nb; b += per) v.push_back(BlockRange{b, std::min(per, nb - b)});
+}
+
 struct CompressShard {
     uint64_t first_block = 0, num_blocks = 0;
     uint64_t in_off = 0, in_len = 0;
     uint8_t *d_in = nullptr, *d_slots = nullptr, *d_stream = nullptr;
     uint32_t* d_bytes = nullptr;
     uint64_t *d_offsets = nullptr, *d_stream_len = nullptr;
-    void* d_scratch = nullptr;
+    void *d_scratch = nullptr, *d_scratch2 = nullptr;
     uint64_t stream_len = 0;
     uint32_t local_hdr = 0;
     uint64_t out_off = 0;
     float kernel_ms = 0.f;
+    // overlapped form only
+    std::vector<CompressChunk> chunks;
+    PipelineStreams ps;
+    float exposed_in_ms = 0.f;
 };
 
 struct DecompressShard {
@@ -598,7 +729,30 @@ struct DecompressShard {
     std::vector<uint64_t> rel_off;
     float kernel_ms = 0.f;
     bool bad = false;
+    // overlapped form only
+    std::vector<DecompressChunk> chunks;
+    PipelineStreams ps;
+    float exposed_in_ms = 0.f;
+    // size chain of the shard (snappy_decompress.c:317-340), walked on demand: blocks [0, walked) have their offsets
+    // (relative to in_off) in ps.h_len[], [walked] holds the end of the last one; walk_at = stream position of block `walked`
+    uint64_t walked = 0, walk_at = 0;
+    bool bad_chain = false;
 };
+
+// extend the walk so that blocks [0, upto) are known; false = the chain leaves the stream
+bool walk_chain(DecompressShard& s, uint64_t upto, const uint8_t* buf, uint64_t in_total)
+{
+    uint64_t* rel = s.ps.h_len;
+    while (s.walked < upto) {
+        if (s.walk_at + 4 > in_total) return false;
+        rel[s.walked] = s.walk_at - s.in_off;
+        s.walk_at += 4 + (uint64_t)le32_host(buf + s.walk_at);
+        if (s.walk_at > in_total) return false;
+        ++s.walked;
+    }
+    rel[s.walked] = s.walk_at - s.in_off;
+    return true;
+}
 
 // "load" phase (dpu_load, snappy_compress.c:541): make the device ready so that the copy and run phases measure
 // copies and kernels -- code object on the device, copy engines and the co-run helper stream initialised.
@@ -616,6 +770,22 @@ int warm_up_device()
     uint32_t probe = 0;
     HIP_TRY(hipMemcpy(&probe, c, sizeof(probe), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(c, &probe, sizeof(probe), hipMemcpyHostToDevice));
+    // the first copy of more than a few KiB in either direction starts the DMA engines (~8 ms, once per process)
+    static thread_local bool engines_started[64] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !engines_started[dev]) {
+        const size_t n = 1u << 20;
+        void *h = nullptr, *d = nullptr;
+        HIP_TRY(hipHostMalloc(&h, n, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&d, n));
+        memset(h, 0, n);
+        HIP_TRY(hipMemcpy(d, h, n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        (void)hipHostFree(h);
+        engines_started[dev] = true;
+    }
     HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
@@ -625,6 +795,396 @@ snappy_status report(const char* where, int rc)
     fprintf(stderr, "snappy_hip: %s failed: %s\n", where, g_last_error.c_str());
     (void)rc;
     return SNAPPY_INVALID_INPUT;   // the reference maps a failed launch to this (snappy_compress.c:618-623)
+}
+
+
+// ---------------------------------------------------------------------------
+// Overlapped form of the drop-in pair.  Each shard is cut into chunks of
+// SNAPPY_HIP_PIPELINE_BLOCKS blocks; chunk k+1 is copied in while chunk k is compressed / decoded and chunk k-1 is
+// copied out, on three streams per shard.  The bytes produced are those of the phased form: chunks are whole blocks,
+// blocks are independent (snappy_compress.c:473, :286), and the host concatenates chunk streams exactly as it
+// concatenates per-device streams.  The enqueue order (kernels of k, then copy-in of k+1, then copy-out of k-1) keeps
+// the overlap when the caller's buffers are pageable and hipMemcpyAsync degrades to a blocking staged copy.
+// program_runtime then holds the EXPOSED parts: copy_in = until the first chunk is on the device, run = from there to
+// the last kernel, copy_out = what is left of the wall time.
+// ---------------------------------------------------------------------------
+snappy_status compress_pipelined(struct host_buffer_context* input, struct host_buffer_context* output, uint32_t block_size,
+                                 struct program_runtime* runtime, std::vector<CompressShard>& sh, int gpus, const uint8_t* hdr,
+                                 uint32_t hdr_len, uint32_t stride, uint64_t chunk_blocks)
+{
+    const uint64_t scratch_bytes = snappy_hip_compress_scratch_bytes();
+    auto pad = [](uint64_t v) { return (v + 255) & ~255ull; };
+
+    // alloc (dpu_alloc, snappy_compress.c:535)
+    double t0 = now_seconds();
+    int rc = for_each_device(gpus, [&](int g) -> int {
+        CompressShard& s = sh[g];
+        HIP_TRY(set_shard_device(g));
+        if (!s.num_blocks) return 0;
+        uint64_t stream_pool = 0, offsets_pool = 0;
+        std::vector<BlockRange> ranges;
+        split_blocks(s.num_blocks, chunk_blocks, ranges);
+        for (auto& fb : ranges) {
+            CompressChunk c;
+            c.first_block = fb.first;
+            c.num_blocks = fb.second;
+            c.in_off = c.first_block * block_size;
+            c.in_len = std::min<uint64_t>(s.in_len - c.in_off, c.num_blocks * (uint64_t)block_size);
+            uint8_t tmp[10];
+            c.local_hdr = snappy_hip_write_header(tmp, (uint32_t)c.in_len, block_size);
+            stream_pool += pad(snappy_hip_stream_bound(c.in_len, block_size));
+            offsets_pool += pad((c.num_blocks + 1) * sizeof(uint64_t));
+            s.chunks.push_back(c);
+        }
+        HIP_TRY(hipMalloc((void**)&s.d_in, s.in_len + 16));
+        HIP_TRY(hipMalloc((void**)&s.d_slots, s.num_blocks * (uint64_t)stride));
+        HIP_TRY(hipMalloc((void**)&s.d_bytes, s.num_blocks * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&s.d_offsets, offsets_pool));
+        HIP_TRY(hipMalloc((void**)&s.d_stream_len, pad(s.chunks.size() * sizeof(uint64_t))));
+        HIP_TRY(hipMalloc((void**)&s.d_stream, stream_pool));
+        HIP_TRY(hipMalloc(&s.d_scratch, scratch_bytes));
+        HIP_TRY(hipMalloc(&s.d_scratch2, scratch_bytes));
+        uint64_t stream_at = 0, offsets_at = 0;
+        for (size_t k = 0; k < s.chunks.size(); ++k) {
+            CompressChunk& c = s.chunks[k];
+            c.d_stream = s.d_stream + stream_at;
+            c.d_offsets = (uint64_t*)((uint8_t*)s.d_offsets + offsets_at);
+            c.d_stream_len = s.d_stream_len + k;
+            stream_at += pad(snappy_hip_stream_bound(c.in_len, block_size));
+            offsets_at += pad((c.num_blocks + 1) * sizeof(uint64_t));
+            HIP_TRY(hipEventCreate(&c.ev_in));
+            HIP_TRY(hipEventCreate(&c.ev_k1));
+            HIP_TRY(hipEventCreate(&c.ev_run));
+        }
+        return 0;
+    });
+    runtime->d_alloc = now_seconds() - t0;
+    if (rc) return report("device allocation", rc);
+
+    // load (dpu_load, :541): code object, copy engines, and this shard's streams with their hardware queues
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        HIP_TRY(set_shard_device(g));
+        if (int r = warm_up_device()) return r;
+        if (!sh[g].num_blocks) return 0;
+        PipelineStreams* ps = nullptr;
+        if (int r = pipeline_streams(g, sh[g].chunks.size(), &ps)) return r;
+        sh[g].ps = *ps;
+        return 0;
+    });
+    runtime->load = now_seconds() - t0;
+    if (rc) return report("code object load", rc);
+
+    // the output buffer: the caller's (finite max) or ours, grown when a chunk does not fit
+    const bool caller_owned = output->buffer && output->max != ~0UL;
+    uint64_t capacity = caller_owned ? output->max : 0;
+    if (!caller_owned) {
+        capacity = 32 + input->length + input->length / 6;      // the reference's own bound (snappy_compress.c:446-449)
+        uint8_t* nbuf = (uint8_t*)realloc(output->buffer, capacity);
+        if (!nbuf) {
+            fprintf(stderr, "snappy_hip: cannot allocate %lu bytes for the output\n", (unsigned long)capacity);
+            return SNAPPY_BUFFER_TOO_SMALL;
+        }
+        output->buffer = nbuf;
+    }
+    if (capacity < hdr_len) {
+        fprintf(stderr, "snappy_hip: output buffer of %lu bytes cannot hold the stream header\n", (unsigned long)capacity);
+        return SNAPPY_BUFFER_TOO_SMALL;
+    }
+    memcpy(output->buffer, hdr, hdr_len);
+    uint64_t total = hdr_len;
+    bool too_small = false;
+    // place chunk c of shard s at `total` and start its copy-out
+    auto copy_out_chunk = [&](CompressShard& s, CompressChunk& c) -> int {
+        const uint64_t body = c.stream_len - c.local_hdr;
+        c.out_off = total;
+        if (total + body > capacity) {
+            if (caller_owned) {
+                too_small = true;
+                total += body;
+                return 0;
+            }
+            HIP_TRY(hipDeviceSynchronize());                      // copies into the old buffer must land before it moves
+            capacity = std::max(total + body, capacity + capacity / 2);
+            uint8_t* nbuf = (uint8_t*)realloc(output->buffer, capacity);
+            if (!nbuf) return fail(SNAPPY_HIP_ERR_RUNTIME, "cannot grow the output buffer");
+            output->buffer = nbuf;
+        }
+        if (!too_small)
+            HIP_TRY(hipMemcpyAsync(output->buffer + c.out_off, c.d_stream + c.local_hdr, body, hipMemcpyDeviceToHost, s.ps.out));
+        total += body;
+        return 0;
+    };
+
+    // the pipeline (:547-704).  Shard 0 knows where its output goes and copies out as it runs; later shards learn their
+    // place once every earlier shard has reported its lengths, and copy out after the join.
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        CompressShard& s = sh[g];
+        HIP_TRY(set_shard_device(g));
+        if (!s.num_blocks) return 0;
+        const size_t n = s.chunks.size();
+        auto copy_in = [&](size_t k) -> int {
+            CompressChunk& c = s.chunks[k];
+            HIP_TRY(hipMemcpyAsync(s.d_in + c.in_off, input->buffer + s.in_off + c.in_off, c.in_len, hipMemcpyHostToDevice, s.ps.in));
+            HIP_TRY(hipEventRecord(c.ev_in, s.ps.in));
+            return 0;
+        };
+        auto finish = [&](size_t k) -> int {
+            CompressChunk& c = s.chunks[k];
+            HIP_TRY(hipEventSynchronize(c.ev_run));
+            c.stream_len = s.ps.h_len[k];
+            return g == 0 ? copy_out_chunk(s, c) : 0;
+        };
+        HIP_TRY(hipEventRecord(s.ps.start, s.ps.in));
+        if (int r = copy_in(0)) return r;
+        for (size_t k = 0; k < n; ++k) {
+            CompressChunk& c = s.chunks[k];
+            // Two launches in flight, on alternating streams with a hash-table scratch each: a launch of one block per
+            // wavefront ends in a tail of half-empty CUs, which the next chunk's wavefronts fill.
+            hipStream_t run = (k & 1) ? s.ps.run2 : s.ps.run;
+            void* scratch = (k & 1) ? s.d_scratch2 : s.d_scratch;
+            HIP_TRY(hipStreamWaitEvent(run, c.ev_in, 0));
+            int r = snappy_hip_compress_blocks(s.d_in + c.in_off, c.in_len, block_size, s.d_slots + c.first_block * (uint64_t)stride,
+                                               stride, s.d_bytes + c.first_block, scratch, scratch_bytes, run);
+            if (r) return r;
+            // scan + gather on a stream of their own: small kernels that crawl beside the next chunk's K1 must not
+            // hold back the K1 launch after that
+            HIP_TRY(hipEventRecord(c.ev_k1, run));
+            HIP_TRY(hipStreamWaitEvent(s.ps.post, c.ev_k1, 0));
+            r = snappy_hip_compact(s.d_slots + c.first_block * (uint64_t)stride, stride, s.d_bytes + c.first_block, c.in_len, block_size,
+                                   c.d_stream, c.d_offsets, c.d_stream_len, s.ps.post);
+            if (r) return r;
+            HIP_TRY(hipMemcpyAsync(&s.ps.h_len[k], c.d_stream_len, sizeof(uint64_t), hipMemcpyDeviceToHost, s.ps.post));
+            HIP_TRY(hipEventRecord(c.ev_run, s.ps.post));
+            if (k + 1 < n)
+                if (int r2 = copy_in(k + 1)) return r2;
+            if (k >= 1)
+                if (int r2 = finish(k - 1)) return r2;
+        }
+        if (int r = finish(n - 1)) return r;
+        HIP_TRY(hipStreamSynchronize(s.ps.out));
+        HIP_TRY(hipEventElapsedTime(&s.exposed_in_ms, s.ps.start, s.chunks[0].ev_in));
+        HIP_TRY(hipEventElapsedTime(&s.kernel_ms, s.chunks[0].ev_in, s.chunks[n - 1].ev_run));
+        if (env_int("SNAPPY_HIP_PIPELINE_TRACE", 0))
+            for (size_t k = 0; k < n; ++k) {
+                float a = 0.f, b = 0.f, c = 0.f;
+                HIP_TRY(hipEventElapsedTime(&a, s.ps.start, s.chunks[k].ev_in));
+                HIP_TRY(hipEventElapsedTime(&b, s.ps.start, s.chunks[k].ev_k1));
+                HIP_TRY(hipEventElapsedTime(&c, s.ps.start, s.chunks[k].ev_run));
+                fprintf(stderr, "chunk %zu: copied in at %.2f ms, compressed at %.2f ms, framed at %.2f ms\n", k, a, b, c);
+            }
+        if (n >= 2) {                                   // the second-to-last launch runs on the other stream and may end later
+            float other = 0.f;
+            HIP_TRY(hipEventElapsedTime(&other, s.chunks[0].ev_in, s.chunks[n - 2].ev_run));
+            s.kernel_ms = std::max(s.kernel_ms, other);
+        }
+        return 0;
+    });
+    if (rc) return report("compress pipeline", rc);
+    if (gpus > 1) {
+        for (int g = 1; g < gpus && !rc; ++g) {
+            CompressShard& s = sh[g];
+            if (!s.num_blocks) continue;
+            if ((rc = (int)set_shard_device(g))) break;
+            for (auto& c : s.chunks)
+                if ((rc = copy_out_chunk(s, c))) break;
+        }
+        if (!rc)
+            rc = for_each_device(gpus, [&](int g) -> int {
+                HIP_TRY(set_shard_device(g));
+                if (g && sh[g].num_blocks) HIP_TRY(hipStreamSynchronize(sh[g].ps.out));
+                return 0;
+            });
+        if (rc) return report("device-to-host copy", rc);
+    }
+    const double wall = now_seconds() - t0;
+    runtime->copy_in = sh[0].exposed_in_ms / 1000.0;
+    runtime->run = sh[0].kernel_ms / 1000.0;
+    runtime->copy_out = std::max(0.0, wall - runtime->copy_in - runtime->run);
+
+    for (int g = 0; g < gpus; ++g)   // analogue of the per-tasklet log lines (dpu-compress/dpu_task.c:88)
+        printf("GPU %d: %f s, %lu bytes\n", g, sh[g].kernel_ms / 1000.0, (unsigned long)sh[g].in_len);
+
+    // free (dpu_free, :707)
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        CompressShard& s = sh[g];
+        HIP_TRY(set_shard_device(g));
+        for (auto& c : s.chunks) {
+            if (c.ev_in) (void)hipEventDestroy(c.ev_in);
+            if (c.ev_k1) (void)hipEventDestroy(c.ev_k1);
+            if (c.ev_run) (void)hipEventDestroy(c.ev_run);
+        }
+        (void)hipFree(s.d_in);
+        (void)hipFree(s.d_slots);
+        (void)hipFree(s.d_bytes);
+        (void)hipFree(s.d_offsets);
+        (void)hipFree(s.d_stream_len);
+        (void)hipFree(s.d_scratch);
+        (void)hipFree(s.d_scratch2);
+        (void)hipFree(s.d_stream);
+        return 0;
+    });
+    runtime->d_free = now_seconds() - t0;
+    if (rc) return report("free", rc);
+    if (too_small) {
+        fprintf(stderr, "snappy_hip: output buffer of %lu bytes cannot hold the %lu-byte stream\n", (unsigned long)output->max,
+                (unsigned long)total);
+        return SNAPPY_BUFFER_TOO_SMALL;
+    }
+    if (!caller_owned) {
+        uint8_t* nbuf = (uint8_t*)realloc(output->buffer, total ? total : 1);
+        if (nbuf) output->buffer = nbuf;
+    }
+    output->length = total;
+    output->curr = output->buffer + total;
+    return SNAPPY_OK;
+}
+
+// Decompress counterpart: sizes are known from the host pre-scan, so the whole pipeline is enqueued without a host
+// round trip; chunk k's plaintext goes straight into its range of output->buffer (snappy_decompress.c:463).
+snappy_status decompress_pipelined(const uint8_t* buf, uint64_t in_total, struct host_buffer_context* output,
+                                   struct program_runtime* runtime, std::vector<DecompressShard>& sh, int gpus, uint32_t bs,
+                                   uint64_t total, uint64_t chunk_blocks)
+{
+    double t0 = now_seconds();
+    int rc = for_each_device(gpus, [&](int g) -> int {
+        DecompressShard& s = sh[g];
+        HIP_TRY(set_shard_device(g));
+        if (!s.num_blocks) return 0;
+        std::vector<BlockRange> ranges;
+        split_blocks(s.num_blocks, chunk_blocks, ranges);
+        for (auto& fb : ranges) {
+            DecompressChunk c;
+            c.first_block = fb.first;
+            c.num_blocks = fb.second;
+            c.out_off = c.first_block * bs;
+            c.out_len = std::min<uint64_t>(s.out_len - c.out_off, c.num_blocks * (uint64_t)bs);
+            HIP_TRY(hipEventCreate(&c.ev_in));
+            HIP_TRY(hipEventCreate(&c.ev_run));
+            s.chunks.push_back(c);
+        }
+        HIP_TRY(hipMalloc((void**)&s.d_stream, s.in_len + 16));
+        HIP_TRY(hipMalloc((void**)&s.d_boff, s.num_blocks * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc((void**)&s.d_out, s.out_len + 16));
+        HIP_TRY(hipMalloc((void**)&s.d_status, s.num_blocks * sizeof(uint32_t)));
+        return 0;
+    });
+    runtime->d_alloc = now_seconds() - t0;
+    if (rc) return report("device allocation", rc);
+
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        DecompressShard& s = sh[g];
+        HIP_TRY(set_shard_device(g));
+        if (int r = warm_up_device()) return r;
+        if (!s.num_blocks) return 0;
+        PipelineStreams* ps = nullptr;
+        if (int r = pipeline_streams(g, s.num_blocks + 1, &ps)) return r;   // page-locked home of the block offsets
+        s.ps = *ps;
+        if (!s.rel_off.empty()) {                                           // chain already walked by the caller
+            memcpy(s.ps.h_len, s.rel_off.data(), s.num_blocks * sizeof(uint64_t));
+            s.ps.h_len[s.num_blocks] = s.in_len;
+            s.walked = s.num_blocks;
+            s.walk_at = s.in_off + s.in_len;
+        }
+        return 0;
+    });
+    runtime->load = now_seconds() - t0;
+    if (rc) return report("code object load", rc);
+
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        DecompressShard& s = sh[g];
+        HIP_TRY(set_shard_device(g));
+        if (!s.num_blocks) return 0;
+        const size_t n = s.chunks.size();
+        const uint64_t* rel = s.ps.h_len;
+        auto copy_out = [&](size_t k) -> int {
+            DecompressChunk& c = s.chunks[k];
+            HIP_TRY(hipStreamWaitEvent(s.ps.out, c.ev_run, 0));
+            HIP_TRY(hipMemcpyAsync(output->buffer + s.out_off + c.out_off, s.d_out + c.out_off, c.out_len, hipMemcpyDeviceToHost, s.ps.out));
+            return 0;
+        };
+        HIP_TRY(hipEventRecord(s.ps.start, s.ps.in));
+        size_t issued = 0;
+        for (size_t k = 0; k < n; ++k) {
+            DecompressChunk& c = s.chunks[k];
+            // the host walks this chunk's part of the size chain while the previous chunk is still being copied in
+            if (!walk_chain(s, c.first_block + c.num_blocks, buf, in_total)) {
+                s.bad_chain = true;
+                break;
+            }
+            c.in_off = rel[c.first_block];
+            c.in_len = rel[c.first_block + c.num_blocks] - c.in_off;
+            HIP_TRY(hipMemcpyAsync(s.d_boff + c.first_block, rel + c.first_block, c.num_blocks * sizeof(uint64_t), hipMemcpyHostToDevice,
+                                   s.ps.in));
+            HIP_TRY(hipMemcpyAsync(s.d_stream + c.in_off, buf + s.in_off + c.in_off, c.in_len, hipMemcpyHostToDevice, s.ps.in));
+            HIP_TRY(hipEventRecord(c.ev_in, s.ps.in));
+            HIP_TRY(hipStreamWaitEvent(s.ps.run, c.ev_in, 0));
+            // block i of the chunk is read at d_stream + d_boff[first + i] (offsets stay relative to the shard's slice)
+            int r = snappy_hip_decompress_blocks(s.d_stream, s.in_len, s.d_boff + c.first_block, c.out_len, bs, s.d_out + c.out_off,
+                                                 s.d_status + c.first_block, s.ps.run);
+            if (r) return r;
+            HIP_TRY(hipEventRecord(c.ev_run, s.ps.run));
+            ++issued;
+            if (k >= 1)
+                if (int r2 = copy_out(k - 1)) return r2;
+        }
+        if (!s.bad_chain && s.walk_at != s.in_off + s.in_len) s.bad_chain = true;    // the chain must end where the slice ends
+        if (issued && !s.bad_chain)
+            if (int r = copy_out(issued - 1)) return r;
+        HIP_TRY(hipStreamSynchronize(s.ps.in));
+        HIP_TRY(hipStreamSynchronize(s.ps.run));
+        HIP_TRY(hipStreamSynchronize(s.ps.out));
+        if (s.bad_chain || !issued) return 0;
+        std::vector<uint32_t> st(s.num_blocks);
+        HIP_TRY(hipMemcpy(st.data(), s.d_status, s.num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < s.num_blocks; ++i)
+            if (st[i] != SNAPPY_HIP_BLOCK_OK) s.bad = true;
+        HIP_TRY(hipEventElapsedTime(&s.exposed_in_ms, s.ps.start, s.chunks[0].ev_in));
+        HIP_TRY(hipEventElapsedTime(&s.kernel_ms, s.chunks[0].ev_in, s.chunks[n - 1].ev_run));
+        return 0;
+    });
+    const double wall = now_seconds() - t0;
+    if (rc) return report("decompress pipeline", rc);
+    runtime->copy_in = sh[0].exposed_in_ms / 1000.0;
+    runtime->run = sh[0].kernel_ms / 1000.0;
+    runtime->copy_out = std::max(0.0, wall - runtime->copy_in - runtime->run);
+
+    for (int g = 0; g < gpus; ++g)
+        printf("GPU %d: %f s, %lu bytes\n", g, sh[g].kernel_ms / 1000.0, (unsigned long)sh[g].in_len);
+
+    t0 = now_seconds();
+    rc = for_each_device(gpus, [&](int g) -> int {
+        DecompressShard& s = sh[g];
+        HIP_TRY(set_shard_device(g));
+        for (auto& c : s.chunks) {
+            if (c.ev_in) (void)hipEventDestroy(c.ev_in);
+            if (c.ev_run) (void)hipEventDestroy(c.ev_run);
+        }
+        (void)hipFree(s.d_stream);
+        (void)hipFree(s.d_boff);
+        (void)hipFree(s.d_out);
+        (void)hipFree(s.d_status);
+        return 0;
+    });
+    runtime->d_free = now_seconds() - t0;
+    if (rc) return report("free", rc);
+    for (auto& s : sh) {
+        if (s.bad_chain) {
+            fprintf(stderr, "snappy_hip: size chain leaves the stream (block %lu of %lu)\n",
+                    (unsigned long)(s.first_block + s.walked), (unsigned long)(s.first_block + s.num_blocks));
+            return SNAPPY_INVALID_INPUT;
+        }
+        if (s.bad) {
+            fprintf(stderr, "snappy_hip: malformed block in the stream\n");
+            return SNAPPY_INVALID_INPUT;
+        }
+    }
+    output->curr = output->buffer + total;
+    return SNAPPY_OK;
 }
 
 }  // namespace
@@ -666,6 +1226,8 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     const uint32_t hdr_len = snappy_hip_write_header(hdr, (uint32_t)n, block_size);   // :523-525
     const uint32_t stride = snappy_hip_slot_stride(block_size);
     runtime->pre += now_seconds() - t0;
+    if (const uint64_t chunk_blocks = pipeline_chunk_blocks(per); chunk_blocks && per > chunk_blocks)
+        return compress_pipelined(input, output, block_size, runtime, sh, gpus, hdr, hdr_len, stride, chunk_blocks);
 
     // alloc (dpu_alloc, :535)
     t0 = now_seconds();
@@ -827,8 +1389,28 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
         fprintf(stderr, "snappy_hip: block size %u in the stream is outside 1..65535\n", bs);
         return SNAPPY_INVALID_INPUT;
     }
-    // host pre-scan of the size chain (:306-341)
     const uint64_t nb = snappy_hip_num_blocks(total, bs);
+    int gpus = requested_gpus();
+    if (gpus <= 0) {
+        fprintf(stderr, "snappy_hip: no HIP device available; the -d path has no CPU fallback\n");
+        return SNAPPY_INVALID_INPUT;
+    }
+    if ((uint64_t)gpus > nb) gpus = (int)nb;
+    // A decode launch takes about as long for 2048 blocks as for 8192 (one block per wavefront either way), so the
+    // overlapped form pays from three chunks per shard upwards.
+    const uint64_t chunk_blocks = pipeline_chunk_blocks((nb + gpus - 1) / gpus);
+    const bool overlapped = chunk_blocks && (nb + gpus - 1) / gpus >= 3 * chunk_blocks;
+    if (overlapped && gpus == 1) {
+        // one shard: the host walks the size chain chunk by chunk inside the pipeline instead of up front
+        std::vector<DecompressShard> one(1);
+        one[0].num_blocks = nb;
+        one[0].in_off = one[0].walk_at = at;
+        one[0].in_len = in_total - at;
+        one[0].out_len = total;
+        runtime->pre += now_seconds() - t0;
+        return decompress_pipelined(buf, in_total, output, runtime, one, 1, bs, total, chunk_blocks);
+    }
+    // host pre-scan of the size chain (:306-341)
     std::vector<uint64_t> off(nb + 1);
     for (uint64_t i = 0; i < nb; ++i) {
         if (at + 4 > in_total) {
@@ -843,12 +1425,6 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
         fprintf(stderr, "snappy_hip: size chain ends at %lu, stream has %lu bytes\n", (unsigned long)at, (unsigned long)in_total);
         return SNAPPY_INVALID_INPUT;
     }
-    int gpus = requested_gpus();
-    if (gpus <= 0) {
-        fprintf(stderr, "snappy_hip: no HIP device available; the -d path has no CPU fallback\n");
-        return SNAPPY_INVALID_INPUT;
-    }
-    if ((uint64_t)gpus > nb) gpus = (int)nb;
     const uint64_t per = (nb + gpus - 1) / gpus;
     std::vector<DecompressShard> sh(gpus);
     for (int g = 0; g < gpus; ++g) {
@@ -865,6 +1441,7 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
         for (uint64_t i = 0; i < s.num_blocks; ++i) s.rel_off[i] = off[s.first_block + i] - s.in_off;
     }
     runtime->pre += now_seconds() - t0;
+    if (overlapped) return decompress_pipelined(buf, in_total, output, runtime, sh, gpus, bs, total, chunk_blocks);
 
     t0 = now_seconds();
     int rc = for_each_device(gpus, [&](int g) -> int {

@@ -263,11 +263,16 @@ def decompress_resident(d_stream, stream_len=None):
 # drop-in pair (host buffers), driven the way dpu_snappy.c's main() drives the *_dpu functions
 # ---------------------------------------------------------------------------
 
-def compress_host(data, block_size=32768):
-    """snappy_compress_gpu on a host buffer -> (status, stream bytes, runtime dict)."""
+def compress_host(data, block_size=32768, out_capacity=None):
+    """snappy_compress_gpu on a host buffer -> (status, stream bytes, runtime dict).  out_capacity: hand over a
+    caller-owned output buffer of that many bytes (finite `max`) instead of letting the callee allocate."""
     a = np.frombuffer(data, dtype=np.uint8).copy() if len(data) else np.zeros(1, dtype=np.uint8)
     inp = HostBufferContext(b"<memory>", a.ctypes.data, a.ctypes.data, len(data), (1 << 64) - 1)
-    out = HostBufferContext(b"<memory>", None, None, 0, (1 << 64) - 1)
+    if out_capacity is None:
+        out = HostBufferContext(b"<memory>", None, None, 0, (1 << 64) - 1)
+    else:
+        buf = libc().malloc(max(1, out_capacity))
+        out = HostBufferContext(b"<memory>", buf, buf, 0, out_capacity)
     rt = ProgramRuntime()
     st = lib().snappy_compress_gpu(ctypes.byref(inp), ctypes.byref(out), block_size, ctypes.byref(rt))
     stream = b""

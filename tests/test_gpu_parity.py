@@ -102,6 +102,51 @@ def test_dropin_pair_sharding_and_concat(shb, shards, monkeypatch):
         assert st == 0 and plain == data, (bs, shards)
 
 
+@pytest.mark.parametrize("chunk_blocks,shards", [(16, 1), (8, 3), (32, 3), (1024, 1), (0, 1)])
+def test_dropin_pair_overlapped_pipeline(shb, chunk_blocks, shards, monkeypatch):
+    """copy-in / kernels / copy-out overlapped chunk by chunk.  Chunks are whole blocks and the host
+    concatenates them like per-device outputs (snappy_compress.c:697-704), so the stream is the oracle's whatever the
+    chunking; 0 = the strictly phased form."""
+    monkeypatch.setenv("SNAPPY_HIP_PIPELINE_BLOCKS", str(chunk_blocks))
+    monkeypatch.setenv("SNAPPY_HIP_NUM_GPUS", str(shards))
+    monkeypatch.setenv("SNAPPY_HIP_OVERSUBSCRIBE", "1")
+    data = datagen.text_random_interleave(golden_bytes("world192.txt"), 3_000_017)
+    for bs in (32768, 1000, 65535):
+        ref = oracle.compress(data, bs, threads=8)
+        st, stream, rt = shb.compress_host(data, bs)
+        assert st == 0 and stream == ref, (bs, chunk_blocks, shards)
+        assert all(v >= 0 for v in rt.values()) and rt["run"] > 0
+        st, plain, rt = shb.decompress_host(ref)
+        assert st == 0 and plain == data, (bs, chunk_blocks, shards)
+        assert all(v >= 0 for v in rt.values()) and rt["run"] > 0
+    # caller-owned output buffer of exactly the right size, and one byte short
+    ref = oracle.compress(data, 32768, threads=8)
+    st, stream, _ = shb.compress_host(data, 32768, out_capacity=len(ref))
+    assert st == 0 and stream == ref
+    st, _, _ = shb.compress_host(data, 32768, out_capacity=len(ref) - 1)
+    assert st == 2                                                   # SNAPPY_BUFFER_TOO_SMALL (dpu_snappy.h:21-25)
+    # a stream that outgrows the reference's output bound (tiny blocks: 9 bytes per 4): the callee grows its buffer
+    small = data[:100_000]
+    ref = oracle.compress(small, 4, threads=8)
+    assert len(ref) > 32 + len(small) + len(small) // 6
+    st, stream, _ = shb.compress_host(small, 4)
+    assert st == 0 and stream == ref
+    st, plain, _ = shb.decompress_host(ref)
+    assert st == 0 and plain == small
+    # malformed block somewhere in a late chunk; a size chain that leaves the stream or stops short of its end
+    good = oracle.compress(data, 32768, threads=8)
+    ref = bytearray(good)
+    ref[len(ref) - 20000] ^= 0xFF
+    st, plain, _ = shb.decompress_host(bytes(ref))
+    assert st != 0 or plain != data
+    st, _, _ = shb.decompress_host(good[:-3])
+    assert st != 0
+    st, _, _ = shb.decompress_host(good + b"\0\0\0\0\0")
+    assert st != 0
+    st, plain, _ = shb.decompress_host(good)
+    assert st == 0 and plain == data
+
+
 def test_dropin_rejects_bad_block_size_and_streams(shb):
     st, _, _ = shb.compress_host(b"x" * 100, 0)
     assert st != 0
