@@ -103,13 +103,6 @@ class Batch:
                  total_len=self.n, block_size=BLOCK_SIZE, header_len=self.hdr, num_blocks=self.nb)])
             for i in range(self.count)]
         self.d_stream_lens = torch.zeros(self.count, dtype=torch.int64, device="cuda")
-        # pipelined mode (SNAPPY_BENCH_OVERLAP=1): the decoder of container i runs on its own stream, capped at
-        # SNAPPY_BENCH_K2_CAP wavefronts, beside the compression of the containers after it
-        self.k2_stream = torch.cuda.Stream()
-        self.h_stream_lens = torch.zeros(self.count, dtype=torch.int64).pin_memory()
-        self.len_ready = [torch.cuda.Event() for _ in container_ids]
-        self.overlap = os.environ.get("SNAPPY_BENCH_OVERLAP", "0") == "1"
-        self.k2_cap = os.environ.get("SNAPPY_BENCH_K2_CAP", "4096")
 
     def _timed(self, key, record, fn):
         if not record:
@@ -138,15 +131,6 @@ class Batch:
             with torch.cuda.stream(side):
                 shb.index_streams(self.descs[i], 1)
                 self.index_done[i].record(side)
-            if self.overlap:
-                self.h_stream_lens[i:i + 1].copy_(self.ws.stream_len, non_blocking=True)
-                self.len_ready[i].record(main)
-                if i >= 1:
-                    self._launch_overlapped_k2(i - 1, record, capped=True)
-        if self.overlap:
-            self._launch_overlapped_k2(self.count - 1, record, capped=False)
-            main.wait_stream(self.k2_stream)
-            return
         self.stream_lens = [int(v) for v in self.d_stream_lens.cpu().tolist()]   # the decoder's launch needs the lengths
         # ---- decompress each stream as soon as its index is ready ----
         for i in range(self.count):
@@ -154,21 +138,6 @@ class Batch:
             self._timed("decompress", record,
                         lambda: shb.decompress_blocks(self.streams[i], self.stream_lens[i], self.boffs[i], self.n,
                                                       BLOCK_SIZE, self.out, self.status))
-
-    def _launch_overlapped_k2(self, j, record, capped):
-        shb, torch = self.shb, self.torch
-        self.len_ready[j].synchronize()                       # container j was framed long ago: no stall
-        self.stream_lens[j] = int(self.h_stream_lens[j])
-        with torch.cuda.stream(self.k2_stream):
-            self.k2_stream.wait_event(self.index_done[j])
-            if capped:
-                os.environ["SNAPPY_HIP_K2_WAVES"] = self.k2_cap
-            try:
-                self._timed("decompress", record,
-                            lambda: shb.decompress_blocks(self.streams[j], self.stream_lens[j], self.boffs[j], self.n,
-                                                          BLOCK_SIZE, self.out, self.status))
-            finally:
-                os.environ.pop("SNAPPY_HIP_K2_WAVES", None)
 
     def verify(self):
         """Outside the timed region: every container round-trips bit-exactly and every block decoded OK."""
