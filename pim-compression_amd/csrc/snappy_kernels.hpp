@@ -2176,62 +2176,63 @@ __device__ __forceinline__ void predecode(uint64_t w, uint32_t pos, uint32_t csz
 // store at once; the deferred stores are made together -- one wait for the whole batch instead of one memory round trip
 // per copy -- when the batch is full, when a copy wants bytes at or above the first deferred destination (`lo`: everything
 // from there on may still be missing), at the end of the window, or before any element the loop does not take.  PMC on the
-// one-copy-at-a-time loop: wavefronts spent 74 % of their cycles waiting on memory, 16 % executing.
-#define K2_DECODE_OR_LEAVE(I)                                                                        \
+// one-copy-at-a-time loop: wavefronts spent 74 % of their cycles waiting on memory, 16 % executing; with the batches the
+// loop is bound by the scalar unit (one SALU instruction per SIMD every four cycles), so the per-element fields come as
+// separate registers read with v_readlane (a VALU slot, of which there are plenty) and the two classes as lane masks:
+// 12 SALU instructions per copy (incl. its share of the batch store) and 8 per literal, down from 18 and 15.
+//   lenv / advv / xlv / offv: per window lane, the element's output length, its compressed advance, the window lane of a
+//   literal's first payload byte, a copy's offset.  cm / lm: lanes that start a copy / literal of the classes above.
+//   s = cp - g (in/out), wlim = wend - g.
+#define K2_TOP(I)                                                                                    \
     "k2_s" I "_%=:\n"                                                                                \
-    "  s_cmp_ge_u32 %[cp], %[wend]\n"                                                                \
+    "  s_cmp_ge_u32 %[s], %[wlim]\n"                                                                 \
     "  s_cbranch_scc1 k2_leave" I "_%=\n"                                                            \
-    "  s_sub_u32 %[s], %[cp], %[g]\n"                                                                \
-    "  v_readlane_b32 %[m], %[meta], %[s]\n"                                                         \
-    "  s_bitcmp1_b32 %[m], 5\n"                                                                      \
+    "  s_bitcmp1_b64 %[cm], %[s]\n"                                                                  \
     "  s_cbranch_scc1 k2_c" I "_%=\n"                                                                \
-    "  s_bitcmp1_b32 %[m], 6\n"                                                                      \
+    "  s_bitcmp1_b64 %[lm], %[s]\n"                                                                  \
     "  s_cbranch_scc0 k2_leave" I "_%=\n"         /* neither class (or rejected by predecode) */     \
     /* ---- literal inside the granule: stored at once ---- */                                       \
-    "  s_lshr_b32 %[len], %[m], 8\n"                                                                 \
-    "  s_add_u32 %[t], %[op], %[len]\n"                                                              \
-    "  s_cmp_gt_u32 %[t], %[outlen]\n"                                                               \
-    "  s_cbranch_scc1 k2_leave" I "_%=\n"         /* would overrun the block's output */             \
-    "  s_bfe_u32 %[hdr], %[m], 0x30002\n"                                                            \
-    "  s_add_u32 %[x], %[s], %[hdr]\n"            /* payload start, as a window lane */              \
+    "  v_readlane_b32 %[len], %[lenv], %[s]\n"                                                       \
+    "  v_readlane_b32 %[x], %[xlv], %[s]\n"       /* payload start, as a window lane */              \
     "  s_bfm_b64 exec, %[len], %[x]\n"            /* len <= 63 here */                               \
     "  s_sub_u32 %[m], %[op], %[x]\n"                                                                \
     "  v_add_u32 %[va], %[m], %[lane]\n"                                                             \
+    "  s_add_u32 %[op], %[op], %[len]\n"                                                             \
+    "  s_cmp_gt_u32 %[op], %[outlen]\n"                                                              \
+    "  s_cbranch_scc1 k2_undo" I "_%=\n"          /* would overrun the block's output */             \
     "  global_store_byte %[va], %[w0], %[win]\n"                                                     \
-    "  s_mov_b64 exec, -1\n"                                                                         \
-    "  s_add_u32 %[cp], %[cp], %[hdr]\n"                                                             \
-    "  s_add_u32 %[cp], %[cp], %[len]\n"                                                             \
-    "  s_mov_b32 %[op], %[t]\n"                                                                      \
+    "  v_readlane_b32 %[adv], %[advv], %[s]\n"                                                       \
+    "  s_add_u32 %[s], %[s], %[adv]\n"                                                               \
     "  s_branch k2_s" I "_%=\n"                                                                      \
     /* ---- copy without overlap, <= 63 bytes ---- */                                                \
     "k2_c" I "_%=:\n"                                                                                \
-    "  s_lshr_b32 %[len], %[m], 8\n"                                                                 \
-    "  s_add_u32 %[t], %[op], %[len]\n"                                                              \
-    "  s_cmp_gt_u32 %[t], %[outlen]\n"                                                               \
-    "  s_cbranch_scc1 k2_leave" I "_%=\n"                                                            \
+    "  v_readlane_b32 %[len], %[lenv], %[s]\n"                                                       \
     "  v_readlane_b32 %[off], %[offv], %[s]\n"                                                       \
     "  s_cmp_gt_u32 %[off], %[op]\n"                                                                 \
     "  s_cbranch_scc1 k2_leave" I "_%=\n"         /* reaches before the block start */               \
     "  s_sub_u32 %[x], %[op], %[off]\n"
 #define K2_NEEDS_DEFERRED(I)                      /* source end above the first deferred destination */\
-    "  s_add_u32 %[hdr], %[x], %[len]\n"                                                             \
-    "  s_cmp_gt_u32 %[hdr], %[lo]\n"                                                                 \
+    "  s_add_u32 %[m], %[x], %[len]\n"                                                               \
+    "  s_cmp_gt_u32 %[m], %[lo]\n"                                                                   \
     "  s_cbranch_scc1 k2_again" I "_%=\n"
-#define K2_ISSUE(VD, PD, PL)                                                                         \
-    "  s_bfe_u32 %[hdr], %[m], 0x30002\n"                                                            \
+#define K2_ISSUE(I, VD, VA, PL)                                                                      \
     "  s_bfm_b64 exec, %[len], 0\n"                                                                  \
     "  v_add_u32 %[va], %[x], %[lane]\n"                                                             \
+    "  v_add_u32 " VA ", %[op], %[lane]\n"        /* where the bytes go, kept until the batch store */\
+    "  s_add_u32 %[op], %[op], %[len]\n"                                                             \
+    "  s_cmp_gt_u32 %[op], %[outlen]\n"                                                              \
+    "  s_cbranch_scc1 k2_undo" I "_%=\n"                                                             \
     "  global_load_ubyte " VD ", %[va], %[win]\n"                                                    \
-    "  s_mov_b64 exec, -1\n"                                                                         \
-    "  s_mov_b32 " PD ", %[op]\n"                                                                    \
     "  s_mov_b32 " PL ", %[len]\n"                                                                   \
-    "  s_add_u32 %[cp], %[cp], %[hdr]\n"                                                             \
-    "  s_mov_b32 %[op], %[t]\n"
-#define K2_STATE(I, NEXT, VD, PD, PL)             /* I copies deferred, I >= 1 */                    \
-    K2_DECODE_OR_LEAVE(I)                                                                            \
+    "  v_readlane_b32 %[adv], %[advv], %[s]\n"                                                       \
+    "  s_add_u32 %[s], %[s], %[adv]\n"
+#define K2_STATE(I, NEXT, VD, VA, PL)             /* I copies deferred, I >= 1 */                    \
+    K2_TOP(I)                                                                                        \
     K2_NEEDS_DEFERRED(I)                                                                             \
-    K2_ISSUE(VD, PD, PL)                                                                             \
+    K2_ISSUE(I, VD, VA, PL)                                                                          \
     "  s_branch k2_s" NEXT "_%=\n"                                                                   \
+    "k2_undo" I "_%=:\n"                                                                             \
+    "  s_sub_u32 %[op], %[op], %[len]\n"                                                             \
     "k2_leave" I "_%=:\n"                                                                            \
     "  s_mov_b32 %[ret], 1\n"                                                                        \
     "  s_waitcnt vmcnt(0)\n"                                                                         \
@@ -2240,59 +2241,61 @@ __device__ __forceinline__ void predecode(uint64_t w, uint32_t pos, uint32_t csz
     "  s_mov_b32 %[ret], 0\n"                                                                        \
     "  s_waitcnt vmcnt(0)\n"                                                                         \
     "  s_branch k2_f" I "_%=\n"
-#define K2_STORE_DEFERRED(I, VD, PD, PL)                                                             \
+#define K2_STORE_DEFERRED(I, VD, VA, PL)                                                             \
     "k2_f" I "_%=:\n"                                                                                \
     "  s_bfm_b64 exec, " PL ", 0\n"                                                                  \
-    "  v_add_u32 %[va], " PD ", %[lane]\n"                                                           \
-    "  global_store_byte %[va], " VD ", %[win]\n"
+    "  global_store_byte " VA ", " VD ", %[win]\n"
 
-__device__ __forceinline__ void k2_fast_elements(uint32_t meta, uint32_t offv, uint32_t w0_lo, uint32_t lane, uint8_t* win,
-                                                 uint32_t g, uint32_t wend, uint32_t out_len, uint32_t& cp, uint32_t& op)
+__device__ __forceinline__ void k2_fast_elements(uint32_t lenv, uint32_t advv, uint32_t xlv, uint32_t offv, uint64_t cm, uint64_t lm,
+                                                 uint32_t w0_lo, uint32_t lane, uint8_t* win, uint32_t wlim, uint32_t out_len,
+                                                 uint32_t& s, uint32_t& op)
 {
 #ifndef SNAPPY_EMU
-    uint32_t s, m, len, t, hdr, x, off, lo, ret;
-    uint32_t pd0, pd1, pd2, pd3, pd4, pd5, pl0, pl1, pl2, pl3, pl4, pl5;
-    uint32_t va, vd0, vd1, vd2, vd3, vd4, vd5;
+    uint32_t m, len, x, off, adv, lo, ret;
+    uint32_t pl0, pl1, pl2, pl3, pl4, pl5;
+    uint32_t va, vd0, vd1, vd2, vd3, vd4, vd5, va0, va1, va2, va3, va4, va5;
     asm volatile(
         // ---- nothing deferred ----
-        K2_DECODE_OR_LEAVE("0")
-        K2_ISSUE("%[vd0]", "%[pd0]", "%[pl0]")
-        "  s_mov_b32 %[lo], %[pd0]\n"
+        K2_TOP("0")
+        "  s_mov_b32 %[lo], %[op]\n"
+        K2_ISSUE("0", "%[vd0]", "%[va0]", "%[pl0]")
         "  s_branch k2_s1_%=\n"
+        "k2_undo0_%=:\n"
+        "  s_sub_u32 %[op], %[op], %[len]\n"
         "k2_leave0_%=:\n"
         "  s_branch k2_done_%=\n"
-        K2_STATE("1", "2", "%[vd1]", "%[pd1]", "%[pl1]")
-        K2_STATE("2", "3", "%[vd2]", "%[pd2]", "%[pl2]")
-        K2_STATE("3", "4", "%[vd3]", "%[pd3]", "%[pl3]")
-        K2_STATE("4", "5", "%[vd4]", "%[pd4]", "%[pl4]")
-        K2_STATE("5", "6", "%[vd5]", "%[pd5]", "%[pl5]")
+        K2_STATE("1", "2", "%[vd1]", "%[va1]", "%[pl1]")
+        K2_STATE("2", "3", "%[vd2]", "%[va2]", "%[pl2]")
+        K2_STATE("3", "4", "%[vd3]", "%[va3]", "%[pl3]")
+        K2_STATE("4", "5", "%[vd4]", "%[va4]", "%[pl4]")
+        K2_STATE("5", "6", "%[vd5]", "%[va5]", "%[pl5]")
         // ---- all six registers in use: store them, then carry on with nothing deferred ----
         "k2_s6_%=:\n"
         "  s_mov_b32 %[ret], 0\n"
         "  s_waitcnt vmcnt(0)\n"
-        K2_STORE_DEFERRED("6", "%[vd5]", "%[pd5]", "%[pl5]")
-        K2_STORE_DEFERRED("5", "%[vd4]", "%[pd4]", "%[pl4]")
-        K2_STORE_DEFERRED("4", "%[vd3]", "%[pd3]", "%[pl3]")
-        K2_STORE_DEFERRED("3", "%[vd2]", "%[pd2]", "%[pl2]")
-        K2_STORE_DEFERRED("2", "%[vd1]", "%[pd1]", "%[pl1]")
-        K2_STORE_DEFERRED("1", "%[vd0]", "%[pd0]", "%[pl0]")
-        "  s_mov_b64 exec, -1\n"
+        K2_STORE_DEFERRED("6", "%[vd5]", "%[va5]", "%[pl5]")
+        K2_STORE_DEFERRED("5", "%[vd4]", "%[va4]", "%[pl4]")
+        K2_STORE_DEFERRED("4", "%[vd3]", "%[va3]", "%[pl3]")
+        K2_STORE_DEFERRED("3", "%[vd2]", "%[va2]", "%[pl2]")
+        K2_STORE_DEFERRED("2", "%[vd1]", "%[va1]", "%[pl1]")
+        K2_STORE_DEFERRED("1", "%[vd0]", "%[va0]", "%[pl0]")
         "  s_cmp_eq_u32 %[ret], 0\n"
         "  s_cbranch_scc1 k2_s0_%=\n"
         "k2_done_%=:\n"
-        : [cp] "+s"(cp), [op] "+s"(op), [s] "=&s"(s), [m] "=&s"(m), [len] "=&s"(len), [t] "=&s"(t), [hdr] "=&s"(hdr), [x] "=&s"(x),
-          [off] "=&s"(off), [lo] "=&s"(lo), [ret] "=&s"(ret), [pd0] "=&s"(pd0), [pd1] "=&s"(pd1), [pd2] "=&s"(pd2), [pd3] "=&s"(pd3),
-          [pd4] "=&s"(pd4), [pd5] "=&s"(pd5), [pl0] "=&s"(pl0), [pl1] "=&s"(pl1), [pl2] "=&s"(pl2), [pl3] "=&s"(pl3), [pl4] "=&s"(pl4),
+        "  s_mov_b64 exec, -1\n"                      // nothing inside the loop depends on exec beyond what it sets itself
+        : [s] "+s"(s), [op] "+s"(op), [m] "=&s"(m), [len] "=&s"(len), [x] "=&s"(x), [off] "=&s"(off), [adv] "=&s"(adv),
+          [lo] "=&s"(lo), [ret] "=&s"(ret), [pl0] "=&s"(pl0), [pl1] "=&s"(pl1), [pl2] "=&s"(pl2), [pl3] "=&s"(pl3), [pl4] "=&s"(pl4),
           [pl5] "=&s"(pl5), [va] "=&v"(va), [vd0] "=&v"(vd0), [vd1] "=&v"(vd1), [vd2] "=&v"(vd2), [vd3] "=&v"(vd3), [vd4] "=&v"(vd4),
-          [vd5] "=&v"(vd5)
-        : [meta] "v"(meta), [offv] "v"(offv), [w0] "v"(w0_lo), [lane] "v"(lane), [win] "s"(win), [g] "s"(g), [wend] "s"(wend),
-          [outlen] "s"(out_len)
+          [vd5] "=&v"(vd5), [va0] "=&v"(va0), [va1] "=&v"(va1), [va2] "=&v"(va2), [va3] "=&v"(va3), [va4] "=&v"(va4), [va5] "=&v"(va5)
+        : [lenv] "v"(lenv), [advv] "v"(advv), [xlv] "v"(xlv), [offv] "v"(offv), [w0] "v"(w0_lo), [lane] "v"(lane), [win] "s"(win),
+          [cm] "s"(cm), [lm] "s"(lm), [wlim] "s"(wlim), [outlen] "s"(out_len)
         : "scc", "memory");
 #else
-    (void)meta; (void)offv; (void)w0_lo; (void)lane; (void)win; (void)g; (void)wend; (void)out_len; (void)cp; (void)op;
+    (void)lenv; (void)advv; (void)xlv; (void)offv; (void)cm; (void)lm; (void)w0_lo; (void)lane; (void)win; (void)wlim;
+    (void)out_len; (void)s; (void)op;
 #endif
 }
-#undef K2_DECODE_OR_LEAVE
+#undef K2_TOP
 #undef K2_NEEDS_DEFERRED
 #undef K2_ISSUE
 #undef K2_STATE
@@ -2353,12 +2356,25 @@ __global__ __launch_bounds__(64) void decompress_blocks_kernel(const uint8_t* __
             __builtin_amdgcn_sched_barrier(0);
             next = window_issue(src, (uint64_t)g + 64 + lane, avail);    // stays in flight during this window
             const uint32_t wend = (csz < g + 64) ? csz : g + 64;
+#ifndef SNAPPY_EMU
+            // operands of the hand-scheduled loop: the pre-decoded fields one register each, the two classes as lane masks
+            const uint32_t e_hdr = (meta >> 2) & 7u, e_len = meta >> 8;
+            const uint32_t advv = e_hdr + ((meta & 3u) ? 0u : e_len);
+            const uint32_t xlv = lane + e_hdr;
+            const uint64_t copy_lanes = kLdsWindow ? 0 : __builtin_amdgcn_ballot_w64((meta & 32u) != 0);
+            const uint64_t literal_lanes = kLdsWindow ? 0 : __builtin_amdgcn_ballot_w64((meta & 64u) != 0);
+#endif
 
             while (cp < wend) {                                          // :232, elements that start in this window
+#ifndef SNAPPY_EMU
                 if (!kLdsWindow) {                                       // the common elements, hand-scheduled
-                    k2_fast_elements(meta, offv, (uint32_t)w0, lane, win, g, wend, out_len, cp, op);
+                    uint32_t rel = cp - g;
+                    k2_fast_elements(e_len, advv, xlv, offv, copy_lanes, literal_lanes, (uint32_t)w0, lane, win, wend - g, out_len,
+                                     rel, op);
+                    cp = g + rel;
                     if (cp >= wend) break;
                 }
+#endif
                 const uint32_t s = cp - g;                               // lane that holds this element's tag
                 const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)meta, (int)s);
                 const uint32_t type = m & 3, hdr = (m >> 2) & 7, len = m >> 8;
