@@ -717,6 +717,24 @@ struct CompressShard {
     std::vector<CompressChunk> chunks;
     PipelineStreams ps;
     float exposed_in_ms = 0.f;
+
+    bool owns_anything() const { return d_in || d_slots || d_bytes || d_offsets || d_stream_len || d_scratch || d_scratch2 || d_stream; }
+    // device memory and per-chunk events (the cached streams stay); safe to call twice
+    void release()
+    {
+        for (auto& c : chunks) {
+            if (c.ev_in) (void)hipEventDestroy(c.ev_in);
+            if (c.ev_k1) (void)hipEventDestroy(c.ev_k1);
+            if (c.ev_run) (void)hipEventDestroy(c.ev_run);
+            c.ev_in = c.ev_k1 = c.ev_run = nullptr;
+        }
+        void** owned[] = {(void**)&d_in, (void**)&d_slots, (void**)&d_bytes, (void**)&d_offsets, (void**)&d_stream_len,
+                          &d_scratch, &d_scratch2, (void**)&d_stream};
+        for (void** q : owned) {
+            if (*q) (void)hipFree(*q);
+            *q = nullptr;
+        }
+    }
 };
 
 struct DecompressShard {
@@ -737,6 +755,50 @@ struct DecompressShard {
     // (relative to in_off) in ps.h_len[], [walked] holds the end of the last one; walk_at = stream position of block `walked`
     uint64_t walked = 0, walk_at = 0;
     bool bad_chain = false;
+
+    bool owns_anything() const { return d_stream || d_boff || d_out || d_status; }
+    void release()
+    {
+        for (auto& c : chunks) {
+            if (c.ev_in) (void)hipEventDestroy(c.ev_in);
+            if (c.ev_run) (void)hipEventDestroy(c.ev_run);
+            c.ev_in = c.ev_run = nullptr;
+        }
+        void** owned[] = {(void**)&d_stream, (void**)&d_boff, (void**)&d_out, (void**)&d_status};
+        for (void** q : owned) {
+            if (*q) (void)hipFree(*q);
+            *q = nullptr;
+        }
+    }
+};
+
+// Error returns leave through this: drain every device a shard used, then give its memory back (the normal path has
+// released everything in its timed "free" phase by then, and release() is idempotent).
+struct CompressCleanup {
+    std::vector<CompressShard>& shards;
+    ~CompressCleanup()
+    {
+        bool any = false;
+        for (auto& s : shards) any = any || s.owns_anything();
+        if (!any) return;
+        for (size_t g = 0; g < shards.size(); ++g) {
+            if (set_shard_device((int)g) == hipSuccess) (void)hipDeviceSynchronize();
+            shards[g].release();
+        }
+    }
+};
+struct DecompressCleanup {
+    std::vector<DecompressShard>& shards;
+    ~DecompressCleanup()
+    {
+        bool any = false;
+        for (auto& s : shards) any = any || s.owns_anything();
+        if (!any) return;
+        for (size_t g = 0; g < shards.size(); ++g) {
+            if (set_shard_device((int)g) == hipSuccess) (void)hipDeviceSynchronize();
+            shards[g].release();
+        }
+    }
 };
 
 // extend the walk so that blocks [0, upto) are known; false = the chain leaves the stream
@@ -1011,19 +1073,7 @@ snappy_status compress_pipelined(struct host_buffer_context* input, struct host_
     rc = for_each_device(gpus, [&](int g) -> int {
         CompressShard& s = sh[g];
         HIP_TRY(set_shard_device(g));
-        for (auto& c : s.chunks) {
-            if (c.ev_in) (void)hipEventDestroy(c.ev_in);
-            if (c.ev_k1) (void)hipEventDestroy(c.ev_k1);
-            if (c.ev_run) (void)hipEventDestroy(c.ev_run);
-        }
-        (void)hipFree(s.d_in);
-        (void)hipFree(s.d_slots);
-        (void)hipFree(s.d_bytes);
-        (void)hipFree(s.d_offsets);
-        (void)hipFree(s.d_stream_len);
-        (void)hipFree(s.d_scratch);
-        (void)hipFree(s.d_scratch2);
-        (void)hipFree(s.d_stream);
+        s.release();
         return 0;
     });
     runtime->d_free = now_seconds() - t0;
@@ -1160,14 +1210,7 @@ snappy_status decompress_pipelined(const uint8_t* buf, uint64_t in_total, struct
     rc = for_each_device(gpus, [&](int g) -> int {
         DecompressShard& s = sh[g];
         HIP_TRY(set_shard_device(g));
-        for (auto& c : s.chunks) {
-            if (c.ev_in) (void)hipEventDestroy(c.ev_in);
-            if (c.ev_run) (void)hipEventDestroy(c.ev_run);
-        }
-        (void)hipFree(s.d_stream);
-        (void)hipFree(s.d_boff);
-        (void)hipFree(s.d_out);
-        (void)hipFree(s.d_status);
+        s.release();
         return 0;
     });
     runtime->d_free = now_seconds() - t0;
@@ -1215,6 +1258,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     // partition: contiguous block ranges per device (snappy_compress.c:494-520)
     const uint64_t per = nb ? (nb + gpus - 1) / gpus : 0;
     std::vector<CompressShard> sh(gpus);
+    CompressCleanup cleanup{sh};
     for (int g = 0; g < gpus; ++g) {
         sh[g].first_block = (uint64_t)g * per;
         const uint64_t last = std::min(nb, sh[g].first_block + per);
@@ -1348,13 +1392,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     rc = for_each_device(gpus, [&](int g) -> int {
         CompressShard& s = sh[g];
         HIP_TRY(set_shard_device(g));
-        (void)hipFree(s.d_in);
-        (void)hipFree(s.d_slots);
-        (void)hipFree(s.d_bytes);
-        (void)hipFree(s.d_offsets);
-        (void)hipFree(s.d_stream_len);
-        (void)hipFree(s.d_scratch);
-        (void)hipFree(s.d_stream);
+        s.release();
         return 0;
     });
     runtime->d_free = now_seconds() - t0;
@@ -1403,6 +1441,7 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
     if (overlapped && gpus == 1) {
         // one shard: the host walks the size chain chunk by chunk inside the pipeline instead of up front
         std::vector<DecompressShard> one(1);
+        DecompressCleanup cleanup{one};
         one[0].num_blocks = nb;
         one[0].in_off = one[0].walk_at = at;
         one[0].in_len = in_total - at;
@@ -1427,6 +1466,7 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
     }
     const uint64_t per = (nb + gpus - 1) / gpus;
     std::vector<DecompressShard> sh(gpus);
+    DecompressCleanup cleanup{sh};
     for (int g = 0; g < gpus; ++g) {
         DecompressShard& s = sh[g];
         s.first_block = (uint64_t)g * per;
@@ -1520,10 +1560,7 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
     rc = for_each_device(gpus, [&](int g) -> int {
         DecompressShard& s = sh[g];
         HIP_TRY(set_shard_device(g));
-        (void)hipFree(s.d_stream);
-        (void)hipFree(s.d_boff);
-        (void)hipFree(s.d_out);
-        (void)hipFree(s.d_status);
+        s.release();
         return 0;
     });
     runtime->d_free = now_seconds() - t0;
