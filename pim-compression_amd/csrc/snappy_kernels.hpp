@@ -2163,14 +2163,13 @@ __device__ __forceinline__ void predecode(uint64_t w, uint32_t pos, uint32_t csz
 // kLdsWindow = false: the decoded block is written straight to its place in global memory and back-references
 //   are read from there (vector memory operations of one wavefront complete in issue order on gfx9-family
 //   hardware, so a load issued after a store to the same bytes observes it); no LDS, 32 waves/CU.
-// K2's element loop for the common elements, hand-scheduled for gfx950 (K2 is instruction-issue bound: 13.3e9 instructions
-// per 2 GiB container, ~40 per copy and ~35 per literal in the compiler's version of this loop; here 25 and 23, with the
-// static conditions folded into two class bits by predecode()).
-// Handles, for elements that start in the current 64-byte window: a literal whose payload lies inside the window
-// (`v_readlane` the pre-decoded header, one exec-masked byte store from the window registers) and a non-overlapping copy of
-// up to 63 bytes (one exec-masked byte load + store; same-wave vector memory operations complete in order, so a later load
-// sees an earlier store).  Returns with cp/op advanced as soon as it meets anything else -- an invalid or truncated element,
-// a literal that runs into the next window, an overlapping or 64-byte copy -- and the C++ loop takes that element.
+// K2's element loop for the common elements, hand-scheduled for gfx950 (the compiler's version of this loop spends ~40
+// instructions per copy and ~35 per literal; the static conditions are folded into two class bits by predecode()).
+// Handles, for elements that start in the current 64-byte window: a literal whose payload lies inside the window (one
+// exec-masked byte store from the window registers) and a non-overlapping copy of up to 63 bytes (one exec-masked byte
+// load and, later, store; same-wave vector memory operations complete in order, so a later load sees an earlier store).
+// Returns with s/op advanced as soon as it meets anything else -- an invalid or truncated element, a literal that runs
+// into the next window, an overlapping or 64-byte copy -- and the C++ loop takes that element.
 // The CPU emulator compiles an empty body: there the C++ loop does everything, which is also the specification.
 // Copies overlap: a copy only ISSUES its load (into one of six data registers) and records where its bytes go; literals
 // store at once; the deferred stores are made together -- one wait for the whole batch instead of one memory round trip
