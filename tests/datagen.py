@@ -92,3 +92,73 @@ def lz_structured(n, seed):
         else:
             out += bytes([int(r.integers(0, 256))]) * int(r.integers(1, 300))
     return bytes(out[:n])
+
+
+# ---------------------------------------------------------------------------
+# Stand-ins for the Silesia files BASELINE.json names (configs 3 and 4).  The files themselves are absent from the
+# reference checkout; the shapes follow the survey: exact byte counts, English prose shuffled at paragraph granularity so
+# that repeats fall outside the 32 KiB block window, a tarred-executables-like mix, a text-heavy mail-like mix.
+# ---------------------------------------------------------------------------
+DICKENS_LIKE_BYTES = 10_192_446      # 312 blocks of 32 KiB
+MOZILLA_LIKE_BYTES = 51_220_480      # 1,564 blocks
+SPAMFILE_LIKE_BYTES = 84_217_482     # 2,571 blocks
+
+
+def _paragraph_shuffle(texts, n, seed):
+    r = rng(seed)
+    paras = []
+    for t in texts:
+        paras += [p + b"\n\n" for p in t.replace(b"\r\n", b"\n").split(b"\n\n") if p]
+    out, have = [], 0
+    while have < n:
+        for k in r.permutation(len(paras)):
+            out.append(paras[int(k)])
+            have += len(paras[int(k)])
+            if have >= n:
+                break
+    return b"".join(out)[:n]
+
+
+def dickens_like(texts):
+    """texts: plrabn12, world192, terror2, alice (bytes)."""
+    return _paragraph_shuffle(texts, DICKENS_LIKE_BYTES, 0xD1C3)
+
+
+def mozilla_like(xml_plain):
+    """40 % xml-derived text, 35 % structured binary records, 25 % incompressible, interleaved in 256 KiB slices."""
+    n = MOZILLA_LIKE_BYTES
+    r = rng(0x4D4F5A)
+    parts = {"xml": xml_plain, "rec": records(4 << 20, seed=0x4D4F), "rnd": None}
+    out = bytearray()
+    pos = {"xml": 0, "rec": 0}
+    while len(out) < n:
+        kind = r.choice(["xml", "rec", "rnd"], p=[0.40, 0.35, 0.25])
+        k = 256 << 10
+        if kind == "rnd":
+            out += r.integers(0, 256, size=k, dtype=np.uint8).tobytes()
+        else:
+            src = parts[kind]
+            p = pos[kind] % max(1, len(src) - k)
+            out += src[p:p + k]
+            pos[kind] += k + int(r.integers(0, 4096))
+    return bytes(out[:n])
+
+
+def spamfile_like(texts):
+    """Text-heavy: shuffled paragraphs with repeated header-like lines in front of every 'message'."""
+    n = SPAMFILE_LIKE_BYTES
+    r = rng(0x5A4D)
+    body = _paragraph_shuffle(texts, 24 << 20, 0x5A4E)
+    out = bytearray()
+    pos = 0
+    msg = 0
+    while len(out) < n:
+        msg += 1
+        out += (b"From user%05d@example.org  Mon Jan  1 00:00:%02d 2001\nReceived: from mail.example.org (10.0.%d.%d)\n"
+                b"X-Spam-Flag: YES\nX-Spam-Level: ********\nSubject: offer %d\n\n"
+                % (int(r.integers(0, 50000)), msg % 60, int(r.integers(0, 256)), int(r.integers(0, 256)), msg))
+        k = int(r.integers(2000, 30000))
+        p = pos % (len(body) - k)
+        out += body[p:p + k]
+        pos += k + int(r.integers(0, 100000))
+    return bytes(out[:n])

@@ -147,6 +147,41 @@ def test_dropin_pair_overlapped_pipeline(shb, chunk_blocks, shards, monkeypatch)
     assert st == 0 and plain == data
 
 
+# ---- BASELINE.json configs 3 and 4 (stand-ins of the absent Silesia files, tests/datagen.py) -------------------------
+
+def _prose():
+    return [golden_bytes(n + ".txt") for n in ("plrabn12", "world192", "terror2", "alice")]
+
+
+def test_baseline_config3_dickens_like(shb):
+    """"dickens.txt (10 MB) compress+decompress on 1 MI355X": 10,192,446 bytes of shuffled prose, 312 blocks."""
+    data = datagen.dickens_like(_prose())
+    assert len(data) == datagen.DICKENS_LIKE_BYTES and shb.num_blocks(len(data), 32768) == 312
+    ref = oracle.compress(data, 32768, threads=8)
+    assert gpu_compress(shb, data, 32768) == ref
+    st, out = gpu_decompress(shb, ref)
+    assert st == 0 and out == data
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 4, 8])
+def test_baseline_config4_block_sharded(shb, gpus, monkeypatch):
+    """"mozilla (51 MB) + spamfile (84 MB) block-sharded across 1/2/4/8 MI355X, host-side concat": contiguous block
+    ranges per device through the drop-in pair (more shards than devices are mapped round-robin onto the GPU(s) present)."""
+    monkeypatch.setenv("SNAPPY_HIP_NUM_GPUS", str(gpus))
+    monkeypatch.setenv("SNAPPY_HIP_OVERSUBSCRIBE", "1")
+    st, xml = oracle.decompress(golden_bytes("xml.snappy"))
+    assert st == 0
+    mozilla = datagen.mozilla_like(xml)
+    spamfile = datagen.spamfile_like(_prose()[:2] + [golden_bytes("coding.txt")])
+    assert (shb.num_blocks(len(mozilla), 32768), shb.num_blocks(len(spamfile), 32768)) == (1564, 2571)
+    for name, data in (("mozilla_like", mozilla), ("spamfile_like", spamfile)):
+        ref = oracle.compress(data, 32768, threads=8)
+        st, stream, rt = shb.compress_host(data, 32768)
+        assert st == 0 and stream == ref, (name, gpus)
+        st, plain, rt = shb.decompress_host(ref)
+        assert st == 0 and plain == data, (name, gpus)
+
+
 def test_dropin_rejects_bad_block_size_and_streams(shb):
     st, _, _ = shb.compress_host(b"x" * 100, 0)
     assert st != 0

@@ -168,3 +168,21 @@ def test_converter_to_original_snappy_framing():
     for bs in (64, 4096, 65535):
         data = golden_bytes("coding.txt")
         assert _decode_raw_snappy(mod.convert(oracle.compress(data, bs))) == data
+
+
+def test_baseline_standins_shapes_and_oracle_roundtrip():
+    """The stand-ins of BASELINE.json configs 3 and 4 have the named sizes / block counts, are deterministic, and the
+    oracle round-trips them (the GPU tests compare against these oracle streams)."""
+    prose = [golden_bytes(n + ".txt") for n in ("plrabn12", "world192", "terror2", "alice")]
+    d = datagen.dickens_like(prose)
+    assert len(d) == 10_192_446 and d == datagen.dickens_like(prose)
+    st, xml = oracle.decompress(golden_bytes("xml.snappy"))
+    assert st == 0
+    m = datagen.mozilla_like(xml)
+    sp = datagen.spamfile_like(prose[:2] + [golden_bytes("coding.txt")])
+    assert (len(m), len(sp)) == (51_220_480, 84_217_482)
+    assert hashlib.sha256(m).hexdigest() == hashlib.sha256(datagen.mozilla_like(xml)).hexdigest()
+    for data in (d, m[:8 << 20], sp[:8 << 20]):
+        stream = oracle.compress(data, 32768, threads=8)
+        st, back = oracle.decompress(stream)
+        assert st == 0 and back == data
