@@ -646,6 +646,14 @@ struct PipelineStreams {
     size_t h_len_count = 0;
 };
 
+// The cached streams and their page-locked scratch are per process, so overlapped calls from several host threads take
+// turns (the reference's entry points are single-threaded and synchronous anyway, snappy_compress.c:618).
+std::mutex* pipeline_mutex()
+{
+    static std::mutex* m = new std::mutex;
+    return m;
+}
+
 int pipeline_streams(int shard, size_t chunks, PipelineStreams** out)
 {
     static PipelineStreams per_shard[64];
@@ -874,6 +882,7 @@ snappy_status compress_pipelined(struct host_buffer_context* input, struct host_
                                  struct program_runtime* runtime, std::vector<CompressShard>& sh, int gpus, const uint8_t* hdr,
                                  uint32_t hdr_len, uint32_t stride, uint64_t chunk_blocks)
 {
+    std::lock_guard<std::mutex> one_at_a_time(*pipeline_mutex());
     const uint64_t scratch_bytes = snappy_hip_compress_scratch_bytes();
     auto pad = [](uint64_t v) { return (v + 255) & ~255ull; };
 
@@ -1098,6 +1107,7 @@ snappy_status decompress_pipelined(const uint8_t* buf, uint64_t in_total, struct
                                    struct program_runtime* runtime, std::vector<DecompressShard>& sh, int gpus, uint32_t bs,
                                    uint64_t total, uint64_t chunk_blocks)
 {
+    std::lock_guard<std::mutex> one_at_a_time(*pipeline_mutex());
     double t0 = now_seconds();
     int rc = for_each_device(gpus, [&](int g) -> int {
         DecompressShard& s = sh[g];
