@@ -170,6 +170,37 @@ def test_converter_to_original_snappy_framing():
         assert _decode_raw_snappy(mod.convert(oracle.compress(data, bs))) == data
 
 
+def test_converter_from_original_snappy_framing():
+    """The opposite direction: a raw stream (here: made from the goldens by the converter above, plus one with elements no
+    block-framed file can hold -- a back-reference across 100 KB and an overlapping run) is decoded and re-framed by the
+    dpu_snappy tool; for the goldens' plaintext at 32 KiB blocks that must reproduce the reference's own .snappy files."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("to_raw_snappy", os.path.join(ROOT, "tools", "to_raw_snappy.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.CLI):
+        pytest.skip("dpu_snappy CLI not built")
+    for name in ("alice", "terror2", "world192"):
+        raw = mod.convert(golden_bytes(name + ".snappy"))
+        assert mod.decode_raw(raw) == golden_bytes(name + ".txt")
+        assert mod.reframe(raw, 32768) == golden_bytes(name + ".snappy")
+    # hand-made raw stream: 100000-byte literal, a COPY_4 reaching back over all of it, an overlapping COPY_1 run
+    lit = golden_bytes("plrabn12.txt")[:100000]
+    n = len(lit) + 64 + 11
+    raw = bytearray(mod.varint(n))
+    raw += bytes([62 << 2]) + (len(lit) - 1).to_bytes(3, "little") + lit           # literal with a 3-byte length
+    raw += bytes([(63 << 2) | 3]) + (100000).to_bytes(4, "little")                  # COPY_4: 64 bytes from offset 100000
+    raw += bytes([((11 - 4) << 2) | 1 | (0 << 5), 3])                               # COPY_1: 11 bytes from offset 3 (overlap)
+    plain = mod.decode_raw(bytes(raw))
+    assert plain == lit + lit[:64] + ((lit[:64][-3:] * 4)[:11])
+    framed = mod.reframe(bytes(raw), 4096)
+    assert framed == oracle.compress(plain, 4096)
+    st, back = oracle.decompress(framed)
+    assert st == 0 and back == plain
+
+
 def test_baseline_standins_shapes_and_oracle_roundtrip():
     """The stand-ins of BASELINE.json configs 3 and 4 have the named sizes / block counts, are deterministic, and the
     oracle round-trips them (the GPU tests compare against these oracle streams)."""
