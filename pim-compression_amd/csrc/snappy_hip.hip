@@ -670,7 +670,18 @@ int pipeline_streams(int shard, size_t chunks, PipelineStreams** out)
         uint32_t* c = nullptr;
         for (hipStream_t st : {p.in, p.run, p.run2, p.post, p.out})
             if (int rc = next_work_counter(&c, st)) return rc;
+        // ... and the first asynchronous copy in either direction on a stream starts a DMA queue of its own (~8 ms)
+        const size_t n = 256u << 10;
+        void *h = nullptr, *d = nullptr;
+        HIP_TRY(hipHostMalloc(&h, n, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&d, n));
+        memset(h, 0, n);
+        HIP_TRY(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, p.in));
+        HIP_TRY(hipStreamSynchronize(p.in));
+        for (hipStream_t st : {p.out, p.post, p.run, p.run2}) HIP_TRY(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(d);
+        (void)hipHostFree(h);
     }
     if (chunks > p.h_len_count) {
         if (p.h_len) (void)hipHostFree(p.h_len);
@@ -914,7 +925,7 @@ snappy_status compress_pipelined(struct host_buffer_context* input, struct host_
         HIP_TRY(hipMalloc((void**)&s.d_stream_len, pad(s.chunks.size() * sizeof(uint64_t))));
         HIP_TRY(hipMalloc((void**)&s.d_stream, stream_pool));
         HIP_TRY(hipMalloc(&s.d_scratch, scratch_bytes));
-        HIP_TRY(hipMalloc(&s.d_scratch2, scratch_bytes));
+        if (s.chunks.size() > 1) HIP_TRY(hipMalloc(&s.d_scratch2, scratch_bytes));
         uint64_t stream_at = 0, offsets_at = 0;
         for (size_t k = 0; k < s.chunks.size(); ++k) {
             CompressChunk& c = s.chunks[k];
@@ -1280,133 +1291,11 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     const uint32_t hdr_len = snappy_hip_write_header(hdr, (uint32_t)n, block_size);   // :523-525
     const uint32_t stride = snappy_hip_slot_stride(block_size);
     runtime->pre += now_seconds() - t0;
-    if (const uint64_t chunk_blocks = pipeline_chunk_blocks(per); chunk_blocks && per > chunk_blocks)
-        return compress_pipelined(input, output, block_size, runtime, sh, gpus, hdr, hdr_len, stride, chunk_blocks);
-
-    // alloc (dpu_alloc, :535)
-    t0 = now_seconds();
-    int rc = for_each_device(gpus, [&](int g) -> int {
-        CompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
-        if (!s.num_blocks) return 0;
-        HIP_TRY(hipMalloc((void**)&s.d_in, s.in_len + 16));
-        HIP_TRY(hipMalloc((void**)&s.d_slots, s.num_blocks * (uint64_t)stride));
-        HIP_TRY(hipMalloc((void**)&s.d_bytes, s.num_blocks * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&s.d_offsets, (s.num_blocks + 1) * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc((void**)&s.d_stream_len, sizeof(uint64_t)));
-        HIP_TRY(hipMalloc((void**)&s.d_stream, snappy_hip_stream_bound(s.in_len, block_size)));
-        HIP_TRY(hipMalloc(&s.d_scratch, snappy_hip_compress_scratch_bytes()));
-        return 0;
-    });
-    runtime->d_alloc = now_seconds() - t0;
-    if (rc) return report("device allocation", rc);
-
-    // load (dpu_load, :541): force the code object onto each device
-    t0 = now_seconds();
-    rc = for_each_device(gpus, [&](int g) -> int {
-        HIP_TRY(set_shard_device(g));
-        return warm_up_device();
-    });
-    runtime->load = now_seconds() - t0;
-    if (rc) return report("code object load", rc);
-
-    // copy in (:547-612)
-    t0 = now_seconds();
-    rc = for_each_device(gpus, [&](int g) -> int {
-        CompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
-        if (s.num_blocks) HIP_TRY(hipMemcpy(s.d_in, input->buffer + s.in_off, s.in_len, hipMemcpyHostToDevice));
-        return 0;
-    });
-    runtime->copy_in = now_seconds() - t0;
-    if (rc) return report("host-to-device copy", rc);
-
-    // run (dpu_launch, :618)
-    t0 = now_seconds();
-    rc = for_each_device(gpus, [&](int g) -> int {
-        CompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
-        if (!s.num_blocks) return 0;
-        hipEvent_t e0, e1;
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, nullptr));
-        int r = snappy_hip_compress_blocks(s.d_in, s.in_len, block_size, s.d_slots, stride, s.d_bytes, s.d_scratch,
-                                           snappy_hip_compress_scratch_bytes(), nullptr);
-        if (r) return r;
-        r = snappy_hip_compact(s.d_slots, stride, s.d_bytes, s.in_len, block_size, s.d_stream, s.d_offsets, s.d_stream_len, nullptr);
-        if (r) return r;
-        HIP_TRY(hipEventRecord(e1, nullptr));
-        HIP_TRY(hipEventSynchronize(e1));
-        HIP_TRY(hipEventElapsedTime(&s.kernel_ms, e0, e1));
-        HIP_TRY(hipEventDestroy(e0));
-        HIP_TRY(hipEventDestroy(e1));
-        return 0;
-    });
-    runtime->run = now_seconds() - t0;
-    if (rc) return report("kernel launch", rc);
-
-    // copy out + host-side concat (:633-704)
-    t0 = now_seconds();
-    rc = for_each_device(gpus, [&](int g) -> int {
-        CompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
-        if (!s.num_blocks) return 0;
-        HIP_TRY(hipMemcpy(&s.stream_len, s.d_stream_len, sizeof(uint64_t), hipMemcpyDeviceToHost));
-        uint8_t tmp[10];
-        s.local_hdr = snappy_hip_write_header(tmp, (uint32_t)s.in_len, block_size);
-        return 0;
-    });
-    if (rc) return report("device-to-host copy", rc);
-    uint64_t total = hdr_len;
-    for (auto& s : sh) {
-        s.out_off = total;
-        if (s.num_blocks) total += s.stream_len - s.local_hdr;
-    }
-    if (output->buffer && output->max != ~0UL) {
-        // caller-owned buffer of stated capacity (e.g. page-locked): use it as is
-        if (total > output->max) {
-            fprintf(stderr, "snappy_hip: output buffer of %lu bytes cannot hold the %lu-byte stream\n", output->max,
-                    (unsigned long)total);
-            return SNAPPY_BUFFER_TOO_SMALL;
-        }
-        output->curr = output->buffer;
-        memcpy(output->buffer, hdr, hdr_len);
-    } else {
-        uint8_t* nbuf = (uint8_t*)realloc(output->buffer, total ? total : 1);
-        if (!nbuf) {
-            fprintf(stderr, "snappy_hip: cannot allocate %lu bytes for the output\n", (unsigned long)total);
-            return SNAPPY_BUFFER_TOO_SMALL;
-        }
-        output->buffer = nbuf;
-        output->curr = nbuf;
-        memcpy(nbuf, hdr, hdr_len);
-    }
-    rc = for_each_device(gpus, [&](int g) -> int {
-        CompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
-        if (s.num_blocks)
-            HIP_TRY(hipMemcpy(output->buffer + s.out_off, s.d_stream + s.local_hdr, s.stream_len - s.local_hdr, hipMemcpyDeviceToHost));
-        return 0;
-    });
-    output->length = total;
-    output->curr = output->buffer + total;
-    runtime->copy_out = now_seconds() - t0;
-    if (rc) return report("device-to-host copy", rc);
-
-    for (int g = 0; g < gpus; ++g)   // analogue of the per-tasklet log lines (dpu-compress/dpu_task.c:88)
-        printf("GPU %d: %f s, %lu bytes\n", g, sh[g].kernel_ms / 1000.0, (unsigned long)sh[g].in_len);
-
-    // free (dpu_free, :707)
-    t0 = now_seconds();
-    rc = for_each_device(gpus, [&](int g) -> int {
-        CompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
-        s.release();
-        return 0;
-    });
-    runtime->d_free = now_seconds() - t0;
-    return rc ? report("free", rc) : SNAPPY_OK;
+    // One code path: a shard is a list of chunks; SNAPPY_HIP_PIPELINE_BLOCKS=0 (or a small shard) makes it one chunk, which
+    // is the strictly phased copy-in / run / copy-out of the reference (snappy_compress.c:547-704).
+    uint64_t chunk_blocks = pipeline_chunk_blocks(per);
+    if (!chunk_blocks || per <= chunk_blocks) chunk_blocks = std::max<uint64_t>(per, 1);
+    return compress_pipelined(input, output, block_size, runtime, sh, gpus, hdr, hdr_len, stride, chunk_blocks);
 }
 
 snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct host_buffer_context* output,
@@ -1491,97 +1380,8 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
         for (uint64_t i = 0; i < s.num_blocks; ++i) s.rel_off[i] = off[s.first_block + i] - s.in_off;
     }
     runtime->pre += now_seconds() - t0;
-    if (overlapped) return decompress_pipelined(buf, in_total, output, runtime, sh, gpus, bs, total, chunk_blocks);
-
-    t0 = now_seconds();
-    int rc = for_each_device(gpus, [&](int g) -> int {
-        DecompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
-        if (!s.num_blocks) return 0;
-        HIP_TRY(hipMalloc((void**)&s.d_stream, s.in_len + 16));
-        HIP_TRY(hipMalloc((void**)&s.d_boff, s.num_blocks * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc((void**)&s.d_out, s.out_len + 16));
-        HIP_TRY(hipMalloc((void**)&s.d_status, s.num_blocks * sizeof(uint32_t)));
-        return 0;
-    });
-    runtime->d_alloc = now_seconds() - t0;
-    if (rc) return report("device allocation", rc);
-
-    t0 = now_seconds();
-    rc = for_each_device(gpus, [&](int g) -> int {
-        HIP_TRY(set_shard_device(g));
-        return warm_up_device();
-    });
-    runtime->load = now_seconds() - t0;
-    if (rc) return report("code object load", rc);
-
-    t0 = now_seconds();
-    rc = for_each_device(gpus, [&](int g) -> int {
-        DecompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
-        if (!s.num_blocks) return 0;
-        HIP_TRY(hipMemcpy(s.d_stream, buf + s.in_off, s.in_len, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(s.d_boff, s.rel_off.data(), s.num_blocks * sizeof(uint64_t), hipMemcpyHostToDevice));
-        return 0;
-    });
-    runtime->copy_in = now_seconds() - t0;
-    if (rc) return report("host-to-device copy", rc);
-
-    t0 = now_seconds();
-    rc = for_each_device(gpus, [&](int g) -> int {
-        DecompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
-        if (!s.num_blocks) return 0;
-        hipEvent_t e0, e1;
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, nullptr));
-        int r = snappy_hip_decompress_blocks(s.d_stream, s.in_len, s.d_boff, s.out_len, bs, s.d_out, s.d_status, nullptr);
-        if (r) return r;
-        HIP_TRY(hipEventRecord(e1, nullptr));
-        HIP_TRY(hipEventSynchronize(e1));
-        HIP_TRY(hipEventElapsedTime(&s.kernel_ms, e0, e1));
-        HIP_TRY(hipEventDestroy(e0));
-        HIP_TRY(hipEventDestroy(e1));
-        return 0;
-    });
-    runtime->run = now_seconds() - t0;
-    if (rc) return report("kernel launch", rc);
-
-    t0 = now_seconds();
-    rc = for_each_device(gpus, [&](int g) -> int {
-        DecompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
-        if (!s.num_blocks) return 0;
-        std::vector<uint32_t> st(s.num_blocks);
-        HIP_TRY(hipMemcpy(st.data(), s.d_status, s.num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (uint64_t i = 0; i < s.num_blocks; ++i)
-            if (st[i] != SNAPPY_HIP_BLOCK_OK) s.bad = true;
-        HIP_TRY(hipMemcpy(output->buffer + s.out_off, s.d_out, s.out_len, hipMemcpyDeviceToHost));   // :463
-        return 0;
-    });
-    runtime->copy_out = now_seconds() - t0;
-    if (rc) return report("device-to-host copy", rc);
-
-    for (int g = 0; g < gpus; ++g)
-        printf("GPU %d: %f s, %lu bytes\n", g, sh[g].kernel_ms / 1000.0, (unsigned long)sh[g].in_len);
-
-    t0 = now_seconds();
-    rc = for_each_device(gpus, [&](int g) -> int {
-        DecompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
-        s.release();
-        return 0;
-    });
-    runtime->d_free = now_seconds() - t0;
-    if (rc) return report("free", rc);
-    for (auto& s : sh)
-        if (s.bad) {
-            fprintf(stderr, "snappy_hip: malformed block in the stream\n");
-            return SNAPPY_INVALID_INPUT;
-        }
-    output->curr = output->buffer + total;
-    return SNAPPY_OK;
+    // one chunk per shard = the strictly phased form (the size chain was walked above, in `pre`)
+    return decompress_pipelined(buf, in_total, output, runtime, sh, gpus, bs, total, overlapped ? chunk_blocks : std::max<uint64_t>(per, 1));
 }
 
 }  // extern "C"
