@@ -728,12 +728,8 @@ struct CompressShard {
     uint32_t* d_bytes = nullptr;
     uint64_t *d_offsets = nullptr, *d_stream_len = nullptr;
     void *d_scratch = nullptr, *d_scratch2 = nullptr;
-    uint64_t stream_len = 0;
-    uint32_t local_hdr = 0;
-    uint64_t out_off = 0;
     float kernel_ms = 0.f;
-    // overlapped form only
-    std::vector<CompressChunk> chunks;
+    std::vector<CompressChunk> chunks;      // one chunk = the phased form
     PipelineStreams ps;
     float exposed_in_ms = 0.f;
 
@@ -766,8 +762,7 @@ struct DecompressShard {
     std::vector<uint64_t> rel_off;
     float kernel_ms = 0.f;
     bool bad = false;
-    // overlapped form only
-    std::vector<DecompressChunk> chunks;
+    std::vector<DecompressChunk> chunks;    // one chunk = the phased form
     PipelineStreams ps;
     float exposed_in_ms = 0.f;
     // size chain of the shard (snappy_decompress.c:317-340), walked on demand: blocks [0, walked) have their offsets
@@ -880,11 +875,12 @@ snappy_status report(const char* where, int rc)
 
 
 // ---------------------------------------------------------------------------
-// Overlapped form of the drop-in pair.  Each shard is cut into chunks of
-// SNAPPY_HIP_PIPELINE_BLOCKS blocks; chunk k+1 is copied in while chunk k is compressed / decoded and chunk k-1 is
-// copied out, on three streams per shard.  The bytes produced are those of the phased form: chunks are whole blocks,
-// blocks are independent (snappy_compress.c:473, :286), and the host concatenates chunk streams exactly as it
-// concatenates per-device streams.  The enqueue order (kernels of k, then copy-in of k+1, then copy-out of k-1) keeps
+// The drop-in pair's device side (phases of snappy_compress.c:528-709 / snappy_decompress.c:306-493), overlapped per
+// SURVEY section 8f row 3.  Each shard is cut into chunks of SNAPPY_HIP_PIPELINE_BLOCKS blocks; chunk k+1 is copied in
+// while chunk k is compressed / decoded and chunk k-1 is framed and copied out, on separate streams.  With one chunk per
+// shard this IS the reference's phased order.  The bytes do not depend on the chunking: chunks are whole blocks, blocks
+// are independent (snappy_compress.c:473, :286), and the host concatenates chunk streams exactly as it concatenates
+// per-device streams.  The enqueue order (kernels of k, then copy-in of k+1, then copy-out of k-1) keeps
 // the overlap when the caller's buffers are pageable and hipMemcpyAsync degrades to a blocking staged copy.
 // program_runtime then holds the EXPOSED parts: copy_in = until the first chunk is on the device, run = from there to
 // the last kernel, copy_out = what is left of the wall time.
