@@ -192,6 +192,17 @@ int snappy_hip_compact(const uint8_t *d_slots, uint32_t slot_stride, const uint3
 int snappy_hip_index_streams(const snappy_hip_stream_desc *d_descs, uint32_t count, void *stream);
 
 /*
+ * Check candidate indexes against the size chains of `count` streams, every link in parallel: a caller that already
+ * holds the block offsets -- the d_offsets array snappy_hip_compact just produced for the same stream, or an index kept
+ * beside the file -- need not repeat the serial walk, but the stream stays the authority: d_descs[i].block_offsets must
+ * hold num_blocks + 1 entries with [0] = header_len, [num_blocks] = stream_len, and the u32 stored at [b] leading
+ * exactly to [b + 1] for every b, which is the result of the walk of snappy_decompress.c:317-340 by induction.
+ * result[0] = SNAPPY_HIP_BLOCK_OK when every link holds, SNAPPY_HIP_BLOCK_INVALID otherwise (then use
+ * snappy_hip_index_streams, which needs no candidate); result[1] = number of links that hold.
+ */
+int snappy_hip_verify_index(const snappy_hip_stream_desc *d_descs, uint32_t count, void *stream);
+
+/*
  * K2: decode every block (semantics of snappy_decompress.c:232-285 on well-formed streams,
  * strict otherwise).  Block i is read at d_stream + d_block_offsets[i] and decoded to
  * d_out + i*block_size; d_status[i] = SNAPPY_HIP_BLOCK_*.

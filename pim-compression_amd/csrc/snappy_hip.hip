@@ -108,18 +108,78 @@ constexpr int kDefaultK1FormLds = 2;    // bulk form for the LDS-table kernel
 constexpr int kDefaultLdsWaves = 768;   // 3 LDS-table wavefronts per CU (3 x 33 KiB) beside 20 global-table ones (3 KiB each: filter + duplicate test)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 
-// Work counters for persistent kernels: a small ring in the code object's own global memory, so launches need no
-// allocation; each launch takes the next slot and zeroes it on its stream (up to 64 launches may be in flight).
-__device__ uint32_t g_work_counters[64 * 16];
+// Work counters for persistent kernels: a ring in the code object's own global memory (one copy per device), so launches
+// need no allocation.  Each launch takes the next slot of its device's ring, zeroes it on its stream and leaves an event
+// behind; a slot is handed out again only after the event of its previous launch has completed (normally long ago: the
+// ring has 256 slots), so two launches in flight never share a counter however many streams the caller uses.
+constexpr uint32_t kWorkCounterSlots = 256;
+__device__ uint32_t g_work_counters[kWorkCounterSlots * 16];      // one counter per 64-byte line
 
-int next_work_counter(uint32_t** out, hipStream_t st)
+struct WorkCounterRing {
+    std::mutex m;
+    uint32_t turn = 0;
+    hipEvent_t busy[kWorkCounterSlots] = {};
+    bool taken[kWorkCounterSlots] = {};      // handed out, launch event not recorded yet
+};
+WorkCounterRing* work_counter_ring(int dev)
 {
-    static std::atomic<uint32_t> turn{0};
+    static WorkCounterRing* rings[64] = {};
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (!rings[dev]) rings[dev] = new WorkCounterRing;             // never destroyed (threads may outlive statics)
+    return rings[dev];
+}
+
+// a zeroed counter for one launch on `st`; call work_counter_launched() right after the launch
+struct WorkCounter {
+    uint32_t* ptr = nullptr;
+    hipEvent_t done = nullptr;
+    WorkCounterRing* ring = nullptr;
+    uint32_t slot = 0;
+};
+int next_work_counter(WorkCounter* out, hipStream_t st)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(SNAPPY_HIP_ERR_ARG, "device index out of range");
     uint32_t* base = nullptr;
     HIP_TRY(hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_work_counters)));
-    uint32_t* c = base + (turn.fetch_add(1) & 63u) * 16;      // one counter per 64-byte line
-    HIP_TRY(hipMemsetAsync(c, 0, sizeof(uint32_t), st));
-    *out = c;
+    WorkCounterRing* ring = work_counter_ring(dev);
+    uint32_t slot;
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::mutex> lock(ring->m);
+        uint32_t tries = 0;
+        do {
+            slot = ring->turn++ % kWorkCounterSlots;
+        } while (ring->taken[slot] && ++tries < kWorkCounterSlots);
+        if (ring->taken[slot]) return fail(SNAPPY_HIP_ERR_RUNTIME, "all work counters are being launched");
+        if (!ring->busy[slot]) HIP_TRY(hipEventCreateWithFlags(&ring->busy[slot], hipEventDisableTiming));
+        ring->taken[slot] = true;
+        ev = ring->busy[slot];
+    }
+    out->ptr = base + slot * 16;
+    out->done = ev;
+    out->ring = ring;
+    out->slot = slot;
+    hipError_t e = hipEventSynchronize(ev);                        // an event never recorded counts as complete
+    if (e == hipSuccess) e = hipMemsetAsync(out->ptr, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) {
+        std::lock_guard<std::mutex> lock(ring->m);
+        ring->taken[slot] = false;
+        return fail(SNAPPY_HIP_ERR_RUNTIME, std::string("work counter: ") + hipGetErrorString(e));
+    }
+    return 0;
+}
+// records the launch's completion event on `st` and releases the slot for reuse behind that event
+int work_counter_launched(const WorkCounter& c, hipStream_t st)
+{
+    const hipError_t e = hipEventRecord(c.done, st);
+    {
+        std::lock_guard<std::mutex> lock(c.ring->m);
+        c.ring->taken[c.slot] = false;
+    }
+    if (e != hipSuccess) return fail(SNAPPY_HIP_ERR_RUNTIME, std::string("hipEventRecord: ") + hipGetErrorString(e));
     return 0;
 }
 
@@ -190,6 +250,7 @@ int env_int(const char* name, int fallback)
 // SNAPPY_HIP_OVERSUBSCRIBE=1 (test hook) allows more shards than devices; shard g then runs on device
 // g % device_count, so the sharding and host-side concat paths can be exercised on a one-GPU box.
 int g_physical_devices = 1;
+int g_base_device = 0;      // the caller's current device when the drop-in pair was entered: shard 0 runs there
 
 int requested_gpus()
 {
@@ -205,7 +266,21 @@ int requested_gpus()
     return have;
 }
 
-hipError_t set_shard_device(int shard) { return hipSetDevice(shard % g_physical_devices); }
+hipError_t set_shard_device(int shard) { return hipSetDevice((g_base_device + shard) % g_physical_devices); }
+
+// The drop-in pair leaves the calling thread's current device as it found it (its shard threads are its own).
+struct CallerDevice {
+    int dev = -1;
+    CallerDevice()
+    {
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+        g_base_device = dev > 0 ? dev : 0;
+    }
+    ~CallerDevice()
+    {
+        if (dev >= 0) (void)hipSetDevice(dev);
+    }
+};
 
 // K1 launchers.  SNAPPY_HIP_K1_AHEAD[_LDS] = look-ahead width of the speculative table reads (0 = serial probes only);
 // SNAPPY_HIP_K1_FORM[_LDS] = 1 selects the masked form (lane-mask resolution of the probes), 2 the bulk form
@@ -557,6 +632,18 @@ int snappy_hip_index_streams(const snappy_hip_stream_desc* d_descs, uint32_t cou
     return SNAPPY_HIP_OK;
 }
 
+int snappy_hip_verify_index(const snappy_hip_stream_desc* d_descs, uint32_t count, void* stream)
+{
+    if (count == 0) return SNAPPY_HIP_OK;
+    if (!d_descs) return fail(SNAPPY_HIP_ERR_ARG, "null descriptor array");
+    const snappy_hip::StreamDesc* dd = reinterpret_cast<const snappy_hip::StreamDesc*>(d_descs);
+    hipLaunchKernelGGL(snappy_hip::verify_index_begin_kernel, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, dd, count);
+    hipLaunchKernelGGL(snappy_hip::verify_index_kernel, dim3(count * snappy_hip::kVerifyGroup), dim3(256), 0, (hipStream_t)stream,
+                       dd, count);
+    HIP_TRY(hipGetLastError());
+    return SNAPPY_HIP_OK;
+}
+
 int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, const uint64_t* d_block_offsets,
                                  uint64_t total_len, uint32_t block_size, uint8_t* d_out, uint32_t* d_status, void* stream)
 {
@@ -570,8 +657,11 @@ int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, c
     // the global-window ones, all drawing blocks from one counter.
     const int variant = env_int("SNAPPY_HIP_DECOMPRESS_VARIANT", kDefaultDecompressVariant);
     hipStream_t st = (hipStream_t)stream;
-    uint32_t* counter = nullptr;
-    if (int rc = next_work_counter(&counter, st)) return rc;
+    // every block's status starts as "not decoded": a block the launch never reaches cannot read back as OK
+    HIP_TRY(hipMemsetAsync(d_status, 0xff, nb * sizeof(uint32_t), st));
+    WorkCounter wc;
+    if (int rc = next_work_counter(&wc, st)) return rc;
+    uint32_t* counter = wc.ptr;
     const uint32_t lds_bytes = (block_size + 15u) & ~15u;
     const uint32_t resident = kGlobalTableWaves;
     uint32_t lds_waves = 0;
@@ -600,7 +690,9 @@ int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, c
         hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<false>, dim3(glob_waves), dim3(64), 0, st, d_stream, stream_len,
                            d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb, counter);
     }
-    HIP_TRY(hipGetLastError());
+    const hipError_t launched = hipGetLastError();
+    if (int rc = work_counter_launched(wc, st)) return rc;       // after the join: the event covers both kernels
+    HIP_TRY(launched);
     return SNAPPY_HIP_OK;
 }
 
@@ -632,10 +724,9 @@ struct DecompressChunk {
 // The compress pipeline keeps six streams busy at once (copy-in, two K1 launches, the LDS-table helper, framing,
 // copy-out).  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on
 // one queue run in enqueue order: measured here, the copy-in of chunk k+1 then waits for the K1 launch of chunk k and the
-// pipeline degenerates to the phased form (38 instead of 52 GB/s on a 3 GiB input).  So the library asks for 8 queues
-// when it is loaded, unless the variable is already set; a process that initialised HIP earlier keeps its setting and
-// loses only the overlap, never bytes.
-__attribute__((constructor)) void ask_for_hardware_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// pipeline degenerates to the phased form (38 instead of 52 GB/s on a 3 GiB input).  The library does NOT touch the
+// process environment: a host program that wants the overlap exports GPU_MAX_HW_QUEUES=8 before its first HIP call (the
+// CLI and the Python binding do); without it only the overlap is lost, never bytes.
 
 // Streams of one shard's pipeline.  Creating a stream costs milliseconds (a hardware queue each), so the sets are made
 // once per process and shard index and kept: a long-lived caller pays for them in its first call only.
@@ -667,9 +758,11 @@ int pipeline_streams(int shard, size_t chunks, PipelineStreams** out)
         HIP_TRY(hipStreamCreateWithFlags(&p.out, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&p.start));
         // a stream gets its hardware queue at first use: use each one now, in the load phase, not under the first chunk
-        uint32_t* c = nullptr;
-        for (hipStream_t st : {p.in, p.run, p.run2, p.post, p.out})
+        for (hipStream_t st : {p.in, p.run, p.run2, p.post, p.out}) {
+            WorkCounter c;
             if (int rc = next_work_counter(&c, st)) return rc;
+            if (int rc = work_counter_launched(c, st)) return rc;
+        }
         // ... and the first asynchronous copy in either direction on a stream starts a DMA queue of its own (~8 ms)
         const size_t n = 256u << 10;
         void *h = nullptr, *d = nullptr;
@@ -841,15 +934,18 @@ int warm_up_device()
     HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel<false>)));
     CoRunResources* cr = nullptr;
     if (int rc = corun_resources(&cr)) return rc;
-    uint32_t* c = nullptr;
+    WorkCounter c;
     if (int rc = next_work_counter(&c, nullptr)) return rc;      // also touches the module's globals
     uint32_t probe = 0;
-    HIP_TRY(hipMemcpy(&probe, c, sizeof(probe), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(c, &probe, sizeof(probe), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(&probe, c.ptr, sizeof(probe), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c.ptr, &probe, sizeof(probe), hipMemcpyHostToDevice));
+    if (int rc = work_counter_launched(c, nullptr)) return rc;
     // the first copy of more than a few KiB in either direction starts the DMA engines (~8 ms, once per process)
-    static thread_local bool engines_started[64] = {};
+    static std::mutex engines_mutex;
+    static bool engines_started[64] = {};                        // per process and device, not per (short-lived) shard thread
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> engines_lock(engines_mutex);
     if (dev >= 0 && dev < 64 && !engines_started[dev]) {
         const size_t n = 1u << 20;
         void *h = nullptr, *d = nullptr;
@@ -864,6 +960,21 @@ int warm_up_device()
     }
     HIP_TRY(hipDeviceSynchronize());
     return 0;
+}
+
+// copy_in / run = the slowest shard's exposed copy-in and kernel time (the shards run side by side, so the phase lasts as
+// long as its slowest member); copy_out = what is left of the section's wall time, so the three still add up to it.
+extern "C++" template <class Shard>
+void shard_phase_times(const std::vector<Shard>& sh, struct program_runtime* runtime, double wall)
+{
+    float in_ms = 0.f, run_ms = 0.f;
+    for (const Shard& s : sh) {
+        in_ms = std::max(in_ms, s.exposed_in_ms);
+        run_ms = std::max(run_ms, s.kernel_ms);
+    }
+    runtime->copy_in = in_ms / 1000.0;
+    runtime->run = run_ms / 1000.0;
+    runtime->copy_out = std::max(0.0, wall - runtime->copy_in - runtime->run);
 }
 
 snappy_status report(const char* where, int rc)
@@ -889,7 +1000,6 @@ snappy_status compress_pipelined(struct host_buffer_context* input, struct host_
                                  struct program_runtime* runtime, std::vector<CompressShard>& sh, int gpus, const uint8_t* hdr,
                                  uint32_t hdr_len, uint32_t stride, uint64_t chunk_blocks)
 {
-    std::lock_guard<std::mutex> one_at_a_time(*pipeline_mutex());
     const uint64_t scratch_bytes = snappy_hip_compress_scratch_bytes();
     auto pad = [](uint64_t v) { return (v + 255) & ~255ull; };
 
@@ -982,7 +1092,16 @@ snappy_status compress_pipelined(struct host_buffer_context* input, struct host_
                 total += body;
                 return 0;
             }
-            HIP_TRY(hipDeviceSynchronize());                      // copies into the old buffer must land before it moves
+            // copies into the old buffer must land before it moves: every shard's copy-out stream, each on its own device
+            // (this runs either on shard 0's thread inside the pipeline or on the caller's thread after the join)
+            int here = 0;
+            HIP_TRY(hipGetDevice(&here));
+            for (int g2 = 0; g2 < gpus; ++g2) {
+                if (!sh[g2].num_blocks || !sh[g2].ps.out) continue;
+                HIP_TRY(set_shard_device(g2));
+                HIP_TRY(hipStreamSynchronize(sh[g2].ps.out));
+            }
+            HIP_TRY(hipSetDevice(here));
             capacity = std::max(total + body, capacity + capacity / 2);
             uint8_t* nbuf = (uint8_t*)realloc(output->buffer, capacity);
             if (!nbuf) return fail(SNAPPY_HIP_ERR_RUNTIME, "cannot grow the output buffer");
@@ -1077,9 +1196,7 @@ snappy_status compress_pipelined(struct host_buffer_context* input, struct host_
         if (rc) return report("device-to-host copy", rc);
     }
     const double wall = now_seconds() - t0;
-    runtime->copy_in = sh[0].exposed_in_ms / 1000.0;
-    runtime->run = sh[0].kernel_ms / 1000.0;
-    runtime->copy_out = std::max(0.0, wall - runtime->copy_in - runtime->run);
+    shard_phase_times(sh, runtime, wall);
 
     for (int g = 0; g < gpus; ++g)   // analogue of the per-tasklet log lines (dpu-compress/dpu_task.c:88)
         printf("GPU %d: %f s, %lu bytes\n", g, sh[g].kernel_ms / 1000.0, (unsigned long)sh[g].in_len);
@@ -1114,7 +1231,6 @@ snappy_status decompress_pipelined(const uint8_t* buf, uint64_t in_total, struct
                                    struct program_runtime* runtime, std::vector<DecompressShard>& sh, int gpus, uint32_t bs,
                                    uint64_t total, uint64_t chunk_blocks)
 {
-    std::lock_guard<std::mutex> one_at_a_time(*pipeline_mutex());
     double t0 = now_seconds();
     int rc = for_each_device(gpus, [&](int g) -> int {
         DecompressShard& s = sh[g];
@@ -1216,9 +1332,7 @@ snappy_status decompress_pipelined(const uint8_t* buf, uint64_t in_total, struct
     });
     const double wall = now_seconds() - t0;
     if (rc) return report("decompress pipeline", rc);
-    runtime->copy_in = sh[0].exposed_in_ms / 1000.0;
-    runtime->run = sh[0].kernel_ms / 1000.0;
-    runtime->copy_out = std::max(0.0, wall - runtime->copy_in - runtime->run);
+    shard_phase_times(sh, runtime, wall);
 
     for (int g = 0; g < gpus; ++g)
         printf("GPU %d: %f s, %lu bytes\n", g, sh[g].kernel_ms / 1000.0, (unsigned long)sh[g].in_len);
@@ -1249,11 +1363,12 @@ snappy_status decompress_pipelined(const uint8_t* buf, uint64_t in_total, struct
 
 }  // namespace
 
-snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host_buffer_context* output, uint32_t block_size,
-                                  struct program_runtime* runtime)
+static snappy_status compress_gpu_body(struct host_buffer_context* input, struct host_buffer_context* output, uint32_t block_size,
+                                       struct program_runtime* runtime)
 {
     double t0 = now_seconds();
     if (!input || !output || !runtime) return SNAPPY_INVALID_INPUT;
+    if (input->length && !input->buffer) return SNAPPY_INVALID_INPUT;
     runtime->d_alloc = runtime->load = runtime->copy_in = runtime->run = runtime->copy_out = runtime->d_free = 0.0;
     if (!block_size_ok(block_size)) {
         fprintf(stderr, "snappy_hip: block size %u is outside 1..65535 (16-bit hash table entries)\n", block_size);
@@ -1294,11 +1409,12 @@ snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host
     return compress_pipelined(input, output, block_size, runtime, sh, gpus, hdr, hdr_len, stride, chunk_blocks);
 }
 
-snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct host_buffer_context* output,
-                                    struct program_runtime* runtime)
+static snappy_status decompress_gpu_body(struct host_buffer_context* input, struct host_buffer_context* output,
+                                         struct program_runtime* runtime)
 {
     double t0 = now_seconds();
     if (!input || !output || !runtime) return SNAPPY_INVALID_INPUT;
+    if (!input->buffer || !input->curr || input->curr < input->buffer) return SNAPPY_INVALID_INPUT;
     runtime->d_alloc = runtime->load = runtime->copy_in = runtime->run = runtime->copy_out = runtime->d_free = 0.0;
 
     // block-size varint (snappy_decompress.c:298-303)
@@ -1322,7 +1438,18 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
         fprintf(stderr, "snappy_hip: block size %u in the stream is outside 1..65535\n", bs);
         return SNAPPY_INVALID_INPUT;
     }
+    if (!output->buffer) {
+        fprintf(stderr, "snappy_hip: output->buffer is NULL (setup_decompression allocates it, snappy_decompress.c:207-209)\n");
+        return SNAPPY_INVALID_INPUT;
+    }
     const uint64_t nb = snappy_hip_num_blocks(total, bs);
+    // the header is untrusted: every block needs at least its u32 size prefix, so a stream of in_total - at bytes cannot
+    // hold more than (in_total - at) / 4 blocks -- checked before anything is sized by nb
+    if (nb > (in_total - at) / 4) {
+        fprintf(stderr, "snappy_hip: header promises %lu blocks, the stream has room for %lu\n", (unsigned long)nb,
+                (unsigned long)((in_total - at) / 4));
+        return SNAPPY_INVALID_INPUT;
+    }
     int gpus = requested_gpus();
     if (gpus <= 0) {
         fprintf(stderr, "snappy_hip: no HIP device available; the -d path has no CPU fallback\n");
@@ -1378,6 +1505,45 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
     runtime->pre += now_seconds() - t0;
     // one chunk per shard = the strictly phased form (the size chain was walked above, in `pre`)
     return decompress_pipelined(buf, in_total, output, runtime, sh, gpus, bs, total, overlapped ? chunk_blocks : std::max<uint64_t>(per, 1));
+}
+
+// The exported pair: one call at a time per process (the cached pipeline streams and their page-locked scratch are per
+// process; the reference's entry points are single-threaded and synchronous anyway, snappy_compress.c:618), the caller's
+// current HIP device restored on every return path, and no C++ exception crosses the C boundary.
+snappy_status snappy_compress_gpu(struct host_buffer_context* input, struct host_buffer_context* output, uint32_t block_size,
+                                  struct program_runtime* runtime)
+{
+    try {
+        std::lock_guard<std::mutex> one_at_a_time(*pipeline_mutex());
+        CallerDevice keep;
+        return compress_gpu_body(input, output, block_size, runtime);
+    } catch (const std::bad_alloc&) {
+        fprintf(stderr, "snappy_hip: out of host memory\n");
+        return SNAPPY_BUFFER_TOO_SMALL;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "snappy_hip: %s\n", e.what());
+        return SNAPPY_INVALID_INPUT;
+    } catch (...) {
+        return SNAPPY_INVALID_INPUT;
+    }
+}
+
+snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct host_buffer_context* output,
+                                    struct program_runtime* runtime)
+{
+    try {
+        std::lock_guard<std::mutex> one_at_a_time(*pipeline_mutex());
+        CallerDevice keep;
+        return decompress_gpu_body(input, output, runtime);
+    } catch (const std::bad_alloc&) {
+        fprintf(stderr, "snappy_hip: out of host memory\n");
+        return SNAPPY_BUFFER_TOO_SMALL;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "snappy_hip: %s\n", e.what());
+        return SNAPPY_INVALID_INPUT;
+    } catch (...) {
+        return SNAPPY_INVALID_INPUT;
+    }
 }
 
 }  // extern "C"

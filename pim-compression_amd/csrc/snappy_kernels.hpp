@@ -2085,6 +2085,51 @@ __global__ __launch_bounds__(64 * kIndexWgWaves) void index_streams_kernel(const
 }
 
 // ---------------------------------------------------------------------------
+// Verified side index.  The size chain is serial only when nothing is known about it.  When the caller already holds a
+// candidate index -- the offsets the compressor's own scan produced, or an index stored beside the file -- every link of
+// the chain can be CHECKED independently: offsets[0] is the header length, and for every block b the u32 stored at
+// offsets[b] must lead exactly to offsets[b + 1], the last one to the end of the stream.  By induction that is the walk of
+// snappy_decompress.c:317-340 with the same result, in one parallel pass over num_blocks + 1 words instead of num_blocks
+// dependent loads.  A candidate that fails any link is rejected as a whole (result[0] = invalid); the caller then walks
+// the chain with index_streams_kernel.  descs[s].block_offsets holds num_blocks + 1 entries here.
+//   result[0] = SNAPPY_HIP_BLOCK_OK / _INVALID, result[1] = number of links that hold (num_blocks when the index is right)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void verify_index_begin_kernel(const StreamDesc* __restrict__ descs, uint32_t count)
+{
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= count) return;
+    const StreamDesc d = descs[s];
+    uint32_t st = kBlockOk;
+    if (d.num_blocks == 0) {
+        if (d.stream_len != d.header_len) st = kBlockInvalid;
+    } else if (d.block_offsets[0] != d.header_len || d.block_offsets[d.num_blocks] != d.stream_len) {
+        st = kBlockInvalid;
+    }
+    d.result[0] = st;
+    d.result[1] = 0;
+}
+
+constexpr uint32_t kVerifyGroup = 64;          // workgroups per stream
+__global__ __launch_bounds__(256) void verify_index_kernel(const StreamDesc* __restrict__ descs, uint32_t count)
+{
+    const uint32_t s = blockIdx.x / kVerifyGroup;
+    if (s >= count) return;
+    const StreamDesc d = descs[s];
+    uint32_t good = 0, bad = 0;
+    for (uint32_t b = (blockIdx.x % kVerifyGroup) * 256 + threadIdx.x; b < d.num_blocks; b += kVerifyGroup * 256) {
+        const uint64_t at = d.block_offsets[b];
+        const uint64_t next = d.block_offsets[b + 1];
+        // at + 4 <= next <= stream_len keeps the load inside the stream whatever the candidate holds
+        if (next > d.stream_len || at > next || next - at < 4 || next - at - 4 != (uint64_t)ld32(d.stream + at))
+            ++bad;
+        else
+            ++good;
+    }
+    if (bad) atomicOr(d.result, kBlockInvalid);
+    if (good) atomicAdd(d.result + 1, good);
+}
+
+// ---------------------------------------------------------------------------
 // K2: decompress.  One wavefront per block.
 //
 //  * The compressed stream is consumed through a 128-byte register window: lane l holds the 8 bytes at

@@ -111,6 +111,10 @@ int main(int argc, char **argv)
 		return -1;
 	}
 	if (use_gpu) {
+		/* the overlapped copy-in / kernel / copy-out pipeline of the library keeps six HIP streams busy; HIP maps
+		 * streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The host program owns its environment, so it
+		 * is set here (before the first HIP call), not by the library. */
+		setenv("GPU_MAX_HW_QUEUES", "8", 0);
 		/* the format's length field is a uint32 (snappy_compress.c:461); HBM is not the limit */
 		input.max = 0xffffffffUL;
 		output.max = 0xffffffffUL;
@@ -140,6 +144,12 @@ int main(int argc, char **argv)
 			output.curr = output.buffer;
 			gettimeofday(&b, NULL);
 			rt.pre = get_runtime(&a, &b);
+		} else if (use_gpu) {
+			/* no page-locked memory (or an out-of-range -b, which the library rejects): the library allocates the
+			 * output itself; setup_compression's 32+n+n/6 is too small for tiny block sizes (snappy_compress.c:446-449) */
+			output.buffer = NULL;
+			output.curr = NULL;
+			output.max = ULONG_MAX;
 		} else {
 			setup_compression(&input, &output, &rt);
 		}

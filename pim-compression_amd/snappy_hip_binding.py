@@ -8,6 +8,11 @@ import os
 
 import numpy as np
 
+# The drop-in pair's overlapped pipeline keeps six HIP streams busy; HIP maps streams onto GPU_MAX_HW_QUEUES hardware
+# queues (default 4).  The host program owns its environment (the library never calls setenv), so this host-side module
+# asks for 8 unless the variable is set already; it takes effect if HIP has not been initialised yet.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsnappy_hip.so")
 
@@ -77,6 +82,8 @@ def lib():
         L.snappy_hip_compact.argtypes = [vp, u32, vp, u64, u32, vp, vp, vp, vp]
         L.snappy_hip_index_streams.restype = ctypes.c_int
         L.snappy_hip_index_streams.argtypes = [vp, u32, vp]
+        L.snappy_hip_verify_index.restype = ctypes.c_int
+        L.snappy_hip_verify_index.argtypes = [vp, u32, vp]
         L.snappy_hip_decompress_blocks.restype = ctypes.c_int
         L.snappy_hip_decompress_blocks.argtypes = [vp, u64, vp, u64, u32, vp, vp, vp]
         L.snappy_compress_gpu.restype = ctypes.c_int
@@ -227,6 +234,12 @@ def index_streams(d_descs, count):
     _check(lib().snappy_hip_index_streams(d_descs.data_ptr(), count, _stream_handle(torch)), "snappy_hip_index_streams")
 
 
+def verify_index(d_descs, count):
+    """Parallel check of candidate indexes (num_blocks + 1 offsets per stream) against the streams' size chains."""
+    import torch
+    _check(lib().snappy_hip_verify_index(d_descs.data_ptr(), count, _stream_handle(torch)), "snappy_hip_verify_index")
+
+
 def decompress_blocks(d_stream, stream_len, d_block_offsets, total_len, block_size, d_out, d_status):
     import torch
     _check(lib().snappy_hip_decompress_blocks(d_stream.data_ptr(), stream_len, d_block_offsets.data_ptr(), total_len,
@@ -283,8 +296,9 @@ def compress_host(data, block_size=32768, out_capacity=None):
     return st, stream, rt.as_dict()
 
 
-def decompress_host(stream):
-    """setup_decompression (reference snappy_decompress.c:187-215) + snappy_decompress_gpu -> (status, bytes, runtime)."""
+def decompress_host(stream, out_len_override=None):
+    """setup_decompression (reference snappy_decompress.c:187-215) + snappy_decompress_gpu -> (status, bytes, runtime).
+    out_len_override: bytes to allocate for the plaintext instead of the header's length (tests with hostile headers)."""
     a = np.frombuffer(stream, dtype=np.uint8).copy()
     # first varint: uncompressed length
     total, shift, used = 0, 0, 0
@@ -299,7 +313,7 @@ def decompress_host(stream):
         shift += 7
     if not ok:
         return SNAPPY_INVALID_INPUT, b"", {}
-    size = ((total + 7) & ~7) | 2047
+    size = (((total + 7) & ~7) | 2047) if out_len_override is None else max(8, out_len_override)
     buf = libc().malloc(size)
     inp = HostBufferContext(b"<memory>", a.ctypes.data, a.ctypes.data + used, a.size, (1 << 64) - 1)
     out = HostBufferContext(b"<memory>", buf, buf, total, (1 << 64) - 1)

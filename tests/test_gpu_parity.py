@@ -147,6 +147,66 @@ def test_dropin_pair_overlapped_pipeline(shb, chunk_blocks, shards, monkeypatch)
     assert st == 0 and plain == data
 
 
+@pytest.mark.parametrize("bs", [1, 7, 16])
+@pytest.mark.parametrize("shards", [2, 5])
+def test_dropin_multi_shard_output_growth_tiny_blocks(shb, bs, shards, monkeypatch):
+    """Tiny blocks outgrow the reference's 32+n+n/6 output bound (snappy_compress.c:446-449: 4-byte prefix + literal header
+    per block), so the callee-owned buffer is re-allocated in the middle of the multi-shard copy-out (post-join loop):
+    every shard's pending device-to-host copies must have landed first.  Several chunks per shard, shards oversubscribed
+    onto the available device(s)."""
+    monkeypatch.setenv("SNAPPY_HIP_NUM_GPUS", str(shards))
+    monkeypatch.setenv("SNAPPY_HIP_OVERSUBSCRIBE", "1")
+    monkeypatch.setenv("SNAPPY_HIP_PIPELINE_BLOCKS", "4096")
+    data = datagen.text_random_interleave(golden_bytes("plrabn12.txt"), 200_003 if bs == 1 else 600_011)
+    ref = oracle.compress(data, bs, threads=8)
+    assert len(ref) > 32 + len(data) + len(data) // 6
+    st, stream, rt = shb.compress_host(data, bs)
+    assert st == 0 and stream == ref, (bs, shards)
+    assert rt["run"] > 0 and rt["copy_in"] >= 0
+    st, plain, _ = shb.decompress_host(ref)
+    assert st == 0 and plain == data, (bs, shards)
+
+
+def test_dropin_hostile_header_is_rejected_not_fatal(shb):
+    """A header that promises 4 Gi blocks of one byte (total 0xffffffff, block size 1) on a 30-byte stream: every block needs
+    its u32 prefix, so the stream cannot hold them -- SNAPPY_INVALID_INPUT, no allocation sized by the header."""
+    hostile = bytes([0xff, 0xff, 0xff, 0xff, 0x0f, 0x01]) + bytes(24)
+    st, _, _ = shb.decompress_host(hostile, out_len_override=16)
+    assert st == 1
+
+
+def test_concurrent_decode_launches_on_many_streams(shb):
+    """Every K2 launch owns its work counter: 96 launches on 12 streams in flight at once (more than the 64 slots the
+    counter ring of round 1 had) decode every block, and a status word never reads back as OK for a block nobody decoded."""
+    import torch
+    data = datagen.text_random_interleave(golden_bytes("world192.txt"), 2_000_003)
+    stream = oracle.compress(data, 4096, threads=8)
+    total, bs, hdr = shb.parse_header(stream[:10])
+    nb = shb.num_blocks(total, bs)
+    d_stream = to_dev(stream)
+    st, plain = shb.decompress_resident(d_stream, stream_len=len(stream))
+    assert st == 0 and bytes(plain.cpu().numpy()) == data
+    offs = np.zeros(nb, dtype=np.int64)
+    at = hdr
+    for i in range(nb):
+        offs[i] = at
+        at += 4 + int.from_bytes(stream[at:at + 4], "little")
+    d_offs = torch.from_numpy(offs).cuda()
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    outs = [torch.zeros(total + 16, dtype=torch.uint8, device="cuda") for _ in range(12)]
+    stats = [torch.zeros(nb, dtype=torch.int32, device="cuda") for _ in range(12)]
+    torch.cuda.synchronize()
+    for rep in range(8):
+        for k, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                shb.decompress_blocks(d_stream, len(stream), d_offs, total, bs, outs[k], stats[k])
+    torch.cuda.synchronize()
+    want = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    for k in range(12):
+        assert int((stats[k] != 0).sum()) == 0, k
+        assert torch.equal(outs[k][:total], want), k
+
+
 # ---- BASELINE.json configs 3 and 4 (stand-ins of the absent Silesia files, tests/datagen.py) -------------------------
 
 def _prose():
