@@ -575,3 +575,178 @@ int oracle_decompress_mt(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t 
 	free(offsets);
 	return status;
 }
+
+/* ---- all-cores baseline with a persistent, pre-faulted workspace (SURVEY 8d "CPU baseline") ----
+ *
+ * oracle_compress_mt / oracle_decompress_mt above allocate their slots per call and concatenate serially, which is
+ * fine for a checker but times page faults and one core's memcpy when used as "the all-cores CPU number".  The
+ * context below is what bench.py's cpu_baseline leg times: every buffer is allocated and touched once in
+ * oracle_mt_create, a call is one pthread launch in which each thread (1) runs the per-block routine of
+ * snappy_compress.c:284-413 over its contiguous block range (the partitioning of snappy_compress.c:494-520) into its own
+ * region, (2) meets the others at a barrier where the region offsets are summed, (3) copies its own region to its place
+ * in the stream -- a parallel concat.  Same bytes as oracle_compress.
+ */
+struct oracle_mt_ctx {
+	uint64_t max_n;
+	uint32_t block_size;
+	int nthreads;
+	uint64_t nblocks_max, per;            /* blocks per thread */
+	uint64_t region_stride;               /* bytes reserved per thread */
+	uint8_t *regions;                     /* nthreads * region_stride */
+	uint64_t *region_len;                 /* bytes each thread produced */
+	uint64_t *region_at;                  /* where each thread's bytes go in the stream */
+	uint64_t *offsets;                    /* decompress: block offsets */
+	pthread_barrier_t barrier;
+};
+
+struct mt2_job {
+	struct oracle_mt_ctx *c;
+	int t;
+	const uint8_t *src;
+	uint64_t n;
+	uint8_t *dst;
+	uint64_t hdr_len, nblocks;
+	uint8_t *out;
+	uint64_t out_len;
+	int status;
+};
+
+void *oracle_mt_create(uint64_t max_n, uint32_t block_size, int nthreads)
+{
+	if (block_size == 0 || nthreads < 1 || max_n > 0xffffffffull)
+		return NULL;
+	if (nthreads > 256)
+		nthreads = 256;
+	struct oracle_mt_ctx *c = (struct oracle_mt_ctx *)calloc(1, sizeof(*c));
+	if (!c)
+		return NULL;
+	c->max_n = max_n;
+	c->block_size = block_size;
+	c->nthreads = nthreads;
+	c->nblocks_max = (max_n + block_size - 1) / block_size;
+	c->per = (c->nblocks_max + nthreads - 1) / nthreads;
+	c->region_stride = c->per * (4 + oracle_max_compressed_length(block_size)) + 64;
+	c->regions = (uint8_t *)malloc((uint64_t)nthreads * c->region_stride);
+	c->region_len = (uint64_t *)calloc(nthreads, sizeof(uint64_t));
+	c->region_at = (uint64_t *)calloc(nthreads, sizeof(uint64_t));
+	c->offsets = (uint64_t *)malloc((c->nblocks_max + 1) * sizeof(uint64_t));
+	if (!c->regions || !c->region_len || !c->region_at || !c->offsets || pthread_barrier_init(&c->barrier, NULL, nthreads)) {
+		free(c->regions);
+		free(c->region_len);
+		free(c->region_at);
+		free(c->offsets);
+		free(c);
+		return NULL;
+	}
+	memset(c->regions, 0x5a, (uint64_t)nthreads * c->region_stride);     /* pre-fault */
+	memset(c->offsets, 0, (c->nblocks_max + 1) * sizeof(uint64_t));
+	return c;
+}
+
+void oracle_mt_destroy(void *ctx)
+{
+	struct oracle_mt_ctx *c = (struct oracle_mt_ctx *)ctx;
+	if (!c)
+		return;
+	pthread_barrier_destroy(&c->barrier);
+	free(c->regions);
+	free(c->region_len);
+	free(c->region_at);
+	free(c->offsets);
+	free(c);
+}
+
+static void *mt2_compress_worker(void *arg)
+{
+	struct mt2_job *j = (struct mt2_job *)arg;
+	struct oracle_mt_ctx *c = j->c;
+	uint16_t table[16384];
+	uint8_t *region = c->regions + (uint64_t)j->t * c->region_stride;
+	uint64_t f = (uint64_t)j->t * c->per, l = f + c->per;
+	if (l > j->nblocks)
+		l = j->nblocks;
+	uint64_t put = 0;
+	for (uint64_t b = f; b < l; b++) {
+		uint64_t start = b * c->block_size;
+		uint32_t todo = (uint32_t)((j->n - start < c->block_size) ? (j->n - start) : c->block_size);
+		put += oracle_compress_block(j->src + start, todo, region + put, table);
+	}
+	c->region_len[j->t] = put;
+	pthread_barrier_wait(&c->barrier);
+	if (j->t == 0) {
+		uint64_t at = j->hdr_len;
+		for (int t = 0; t < c->nthreads; t++) {
+			c->region_at[t] = at;
+			at += c->region_len[t];
+		}
+	}
+	pthread_barrier_wait(&c->barrier);
+	memcpy(j->dst + c->region_at[j->t], region, put);
+	return NULL;
+}
+
+/* returns the stream length, 0 on failure; dst_cap >= oracle_compress_bound(n, block_size) */
+uint64_t oracle_mt_compress(void *ctx, const uint8_t *src, uint64_t n, uint8_t *dst, uint64_t dst_cap)
+{
+	struct oracle_mt_ctx *c = (struct oracle_mt_ctx *)ctx;
+	if (!c || n > c->max_n || dst_cap < oracle_compress_bound(n, c->block_size))
+		return 0;
+	uint64_t nblocks = (n + c->block_size - 1) / c->block_size;
+	uint64_t hdr = oracle_write_header(dst, (uint32_t)n, c->block_size);
+	pthread_t tid[256];
+	struct mt2_job jobs[256];
+	for (int t = 0; t < c->nthreads; t++) {
+		jobs[t] = (struct mt2_job){ .c = c, .t = t, .src = src, .n = n, .dst = dst, .hdr_len = hdr, .nblocks = nblocks };
+		pthread_create(&tid[t], NULL, mt2_compress_worker, &jobs[t]);
+	}
+	for (int t = 0; t < c->nthreads; t++)
+		pthread_join(tid[t], NULL);
+	return c->region_at[c->nthreads - 1] + c->region_len[c->nthreads - 1];
+}
+
+static void *mt2_decompress_worker(void *arg)
+{
+	struct mt2_job *j = (struct mt2_job *)arg;
+	struct oracle_mt_ctx *c = j->c;
+	uint64_t f = (uint64_t)j->t * c->per, l = f + c->per;
+	if (l > j->nblocks)
+		l = j->nblocks;
+	j->status = ORACLE_OK;
+	for (uint64_t b = f; b < l; b++) {
+		uint64_t at = c->offsets[b];
+		uint64_t ostart = b * c->block_size;
+		uint64_t olen = (j->out_len - ostart < c->block_size) ? (j->out_len - ostart) : c->block_size;
+		int st = decode_block(j->src, at + 4, at + 4 + le32(j->src + at), j->n, j->out + ostart, olen);
+		if (st != ORACLE_OK)
+			j->status = st;
+	}
+	return NULL;
+}
+
+/* the host pre-scan of the size chain (snappy_decompress.c:317-340) stays serial and inside the call, as in the reference */
+int oracle_mt_decompress(void *ctx, const uint8_t *src, uint64_t n, uint8_t *out, uint64_t out_cap)
+{
+	struct oracle_mt_ctx *c = (struct oracle_mt_ctx *)ctx;
+	uint32_t total, bs;
+	uint32_t hdr = c ? oracle_read_header(src, n, &total, &bs) : 0;
+	if (!hdr || bs != c->block_size || (uint64_t)total > c->max_n)
+		return ORACLE_INVALID_INPUT;
+	if ((uint64_t)total > out_cap)
+		return ORACLE_BUFFER_TOO_SMALL;
+	uint64_t nblocks = ((uint64_t)total + bs - 1) / bs;
+	if (oracle_index_blocks(src, n, c->offsets, nblocks) != (int64_t)nblocks)
+		return ORACLE_INVALID_INPUT;
+	pthread_t tid[256];
+	struct mt2_job jobs[256];
+	for (int t = 0; t < c->nthreads; t++) {
+		jobs[t] = (struct mt2_job){ .c = c, .t = t, .src = src, .n = n, .nblocks = nblocks, .out = out, .out_len = total };
+		pthread_create(&tid[t], NULL, mt2_decompress_worker, &jobs[t]);
+	}
+	int status = ORACLE_OK;
+	for (int t = 0; t < c->nthreads; t++) {
+		pthread_join(tid[t], NULL);
+		if (jobs[t].status != ORACLE_OK)
+			status = jobs[t].status;
+	}
+	return status;
+}

@@ -119,6 +119,15 @@ def num_blocks(n, block_size):
     return int(lib().snappy_hip_num_blocks(n, block_size))
 
 
+def shard_block_range(num_blocks_total, shards, shard):
+    """(first_block, block_count) of `shard` when a file of `num_blocks_total` blocks is split over `shards` devices: the
+    contiguous ranges of ceil(B / G) blocks that snappy_compress_gpu / snappy_decompress_gpu use (csrc/snappy_hip.hip),
+    i.e. the partitioning of the reference's input_blocks_per_dpu (snappy_compress.c:494-520)."""
+    per = (num_blocks_total + shards - 1) // shards if num_blocks_total else 0
+    first = min(num_blocks_total, shard * per)
+    return first, min(num_blocks_total, first + per) - first
+
+
 def write_header(total_len, block_size):
     buf = (ctypes.c_uint8 * 10)()
     k = lib().snappy_hip_write_header(buf, total_len, block_size)
@@ -145,7 +154,8 @@ def _stream_handle(torch):
 class CompressWorkspace:
     """Device buffers for compressing containers of up to `max_len` bytes at `block_size`."""
 
-    def __init__(self, max_len, block_size, device="cuda"):
+    def __init__(self, max_len, block_size, device="cuda", scratch=True):
+        """scratch=False: no hash-table workspace of its own (a batch launch uses one workspace's scratch for all)."""
         import torch
         self._torch = torch
         self.block_size = block_size
@@ -156,9 +166,9 @@ class CompressWorkspace:
         self.block_bytes = torch.empty(max(nb, 1), dtype=torch.int32, device=device)
         self.offsets = torch.empty(nb + 1, dtype=torch.int64, device=device)
         self.stream_len = torch.zeros(1, dtype=torch.int64, device=device)
-        self.scratch_bytes = int(lib().snappy_hip_compress_scratch_bytes())
-        self.scratch = torch.empty(self.scratch_bytes + 256, dtype=torch.uint8, device=device)
-        self.scratch_ptr = (self.scratch.data_ptr() + 255) & ~255
+        self.scratch_bytes = int(lib().snappy_hip_compress_scratch_bytes()) if scratch else 0
+        self.scratch = torch.empty(self.scratch_bytes + 256, dtype=torch.uint8, device=device) if scratch else None
+        self.scratch_ptr = ((self.scratch.data_ptr() + 255) & ~255) if scratch else 0
 
     def lds_form_blocks(self):
         """Blocks of the last compress_blocks() launch that were taken by the LDS-table wavefronts (statistics)."""

@@ -327,6 +327,17 @@ int emu_decompress_variant(const uint8_t* stream, uint64_t stream_len, uint32_t 
     return 0;
 }
 
+// Runs verify_index_begin_kernel + verify_index_kernel on a candidate index of num_blocks + 1 offsets.
+void emu_verify_index(const uint8_t* stream, uint64_t stream_len, uint64_t* offsets, uint32_t total_len, uint32_t block_size,
+                      uint32_t header_len, uint32_t* result)
+{
+    const uint32_t nb = block_size ? (uint32_t)(((uint64_t)total_len + block_size - 1) / block_size) : 0;
+    result[0] = result[1] = 7;
+    snappy_hip::StreamDesc d{stream, stream_len, offsets, result, total_len, block_size, header_len, nb};
+    emu::launch(1, 64, [&] { snappy_hip::verify_index_begin_kernel(&d, 1); });
+    emu::launch(snappy_hip::kVerifyGroup, 256, [&] { snappy_hip::verify_index_kernel(&d, 1); });
+}
+
 int emu_decompress(const uint8_t* stream, uint64_t stream_len, uint32_t total_len, uint32_t block_size, uint32_t header_len,
                    uint8_t* out)
 {

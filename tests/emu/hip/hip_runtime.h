@@ -78,3 +78,9 @@ static inline uint32_t atomicAdd(uint32_t* p, uint32_t v)
     *p = old + v;
     return old;
 }
+static inline uint32_t atomicOr(uint32_t* p, uint32_t v)
+{
+    const uint32_t old = *p;
+    *p = old | v;
+    return old;
+}

@@ -36,6 +36,9 @@ def lib():
         L.emu_decompress_variant.restype = ctypes.c_int
         L.emu_decompress_variant.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                              ctypes.c_void_p, ctypes.c_int]
+        L.emu_verify_index.restype = None
+        L.emu_verify_index.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                       ctypes.c_uint32, ctypes.c_void_p]
         _LIB = L
     return _LIB
 
@@ -57,3 +60,12 @@ def decompress(stream, total_len, block_size, header_len, variant=1):
     out = np.zeros(max(total_len, 1) + 16, dtype=np.uint8)
     st = lib().emu_decompress_variant(a.ctypes.data, a.size, total_len, block_size, header_len, out.ctypes.data, variant)
     return st, out[:total_len].tobytes()
+
+
+def verify_index(stream, offsets, total_len, block_size, header_len):
+    """verify_index kernels on a candidate index (num_blocks + 1 offsets) -> (status, links that hold)."""
+    a = np.frombuffer(stream, dtype=np.uint8).copy()
+    offs = np.ascontiguousarray(np.asarray(offsets, dtype=np.uint64))
+    res = np.zeros(2, dtype=np.uint32)
+    lib().emu_verify_index(a.ctypes.data, a.size, offs.ctypes.data, total_len, block_size, header_len, res.ctypes.data)
+    return int(res[0]), int(res[1])

@@ -35,6 +35,13 @@ def lib():
         L.oracle_decompress_mt.argtypes = [u8p, ctypes.c_uint64, u8p, ctypes.c_uint64, ctypes.c_int]
         L.oracle_index_blocks.restype = ctypes.c_int64
         L.oracle_index_blocks.argtypes = [u8p, ctypes.c_uint64, u8p, ctypes.c_uint64]
+        L.oracle_mt_create.restype = ctypes.c_void_p
+        L.oracle_mt_create.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int]
+        L.oracle_mt_destroy.argtypes = [ctypes.c_void_p]
+        L.oracle_mt_compress.restype = ctypes.c_uint64
+        L.oracle_mt_compress.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, u8p, ctypes.c_uint64]
+        L.oracle_mt_decompress.restype = ctypes.c_int
+        L.oracle_mt_decompress.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, u8p, ctypes.c_uint64]
         _LIB = L
     return _LIB
 
@@ -89,3 +96,34 @@ def index_blocks(stream):
     if got < 0:
         raise ValueError("bad chain")
     return offs[:nb]
+
+
+class MtContext:
+    """All-cores oracle with a persistent, pre-faulted workspace (bench.py's cpu_baseline leg): compress() / decompress()
+    work on caller-owned numpy buffers that were allocated and touched beforehand, so a timed call measures the codec
+    threads and their parallel concat only."""
+
+    def __init__(self, max_n, block_size, threads):
+        self.block_size, self.threads = block_size, threads
+        self.ctx = lib().oracle_mt_create(max_n, block_size, threads)
+        if not self.ctx:
+            raise MemoryError("oracle_mt_create failed")
+        self.bound = int(lib().oracle_compress_bound(max_n, block_size))
+
+    def compress_into(self, src, dst):
+        """src, dst: contiguous uint8 numpy arrays (dst of at least self.bound bytes); returns the stream length."""
+        n = lib().oracle_mt_compress(self.ctx, src.ctypes.data, src.size, dst.ctypes.data, dst.size)
+        if n == 0:
+            raise RuntimeError("oracle_mt_compress failed")
+        return int(n)
+
+    def decompress_into(self, stream, stream_len, out):
+        return int(lib().oracle_mt_decompress(self.ctx, stream.ctypes.data, stream_len, out.ctypes.data, out.size))
+
+    def close(self):
+        if self.ctx:
+            lib().oracle_mt_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        self.close()

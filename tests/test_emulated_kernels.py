@@ -88,3 +88,35 @@ def test_emulated_decoder_is_strict():
     good = oracle.compress(b"hello hello hello hello", 32768)
     st, _ = emu.decompress(good[:-1], 23, 32768, 4)
     assert st == 1
+
+
+def test_emulated_verify_index_accepts_the_chain_and_nothing_else():
+    """snappy_hip_verify_index's kernels: a candidate index passes iff it is exactly the walk of the size chain
+    (snappy_decompress.c:317-340); every kind of wrong candidate is rejected as a whole."""
+    import numpy as np
+    data = datagen.text_random_interleave(golden_bytes("plrabn12.txt"), 300_000)
+    for bs in (32768, 1000, 65535, 7):
+        stream = oracle.compress(data if bs > 7 else data[:20_000], bs)
+        total, got_bs, hdr = oracle.read_header(stream)
+        nb = (total + got_bs - 1) // got_bs
+        good = np.concatenate([oracle.index_blocks(stream), np.array([len(stream)], dtype=np.uint64)])
+        assert emu.verify_index(stream, good, total, got_bs, hdr) == (0, nb)
+        for k in sorted({0, 1, nb // 2, nb - 1, nb}):
+            for delta in (1, -1, 4, 1 << 33):
+                bad = good.copy()
+                bad[k] = np.uint64((int(bad[k]) + delta) & ((1 << 64) - 1))
+                st, links = emu.verify_index(stream, bad, total, got_bs, hdr)
+                assert st != 0 and links < nb, (bs, k, delta)
+        # a stream cut short, or with bytes appended, does not match the index of the intact one
+        assert emu.verify_index(stream[:-1], good, total, got_bs, hdr)[0] != 0
+        assert emu.verify_index(stream + b"\0", good, total, got_bs, hdr)[0] != 0
+        # a corrupted size field breaks exactly the links around it
+        if nb >= 3:
+            broken = bytearray(stream)
+            broken[int(good[1])] ^= 0x01
+            st, links = emu.verify_index(bytes(broken), good, total, got_bs, hdr)
+            assert st != 0 and links == nb - 1
+    empty = oracle.compress(b"", 32768)
+    total, got_bs, hdr = oracle.read_header(empty)
+    assert emu.verify_index(empty, np.array([hdr], dtype=np.uint64), total, got_bs, hdr)[0] == 0
+    assert emu.verify_index(empty + b"x", np.array([hdr], dtype=np.uint64), total, got_bs, hdr)[0] != 0
