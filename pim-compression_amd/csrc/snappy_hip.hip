@@ -107,6 +107,8 @@ constexpr int kDefaultLdsHeadStart = 6; // ~20 us for the LDS-table workgroups t
 constexpr int kDefaultK1FormLds = 2;    // bulk form for the LDS-table kernel
 constexpr int kDefaultLdsWaves = 768;   // 3 LDS-table wavefronts per CU (3 x 33 KiB) beside 20 global-table ones (3 KiB each: filter + duplicate test)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
+constexpr uint32_t kCus = 256, kLdsPerCu = 160u << 10, kWaveSlotsPerCu = 32;
+constexpr int kDefaultPairPerCu = 0;    // two-wavefront LDS-table workgroups per CU beside the global-table wavefronts (0 = round 1's one-wavefront LDS-table kernel)
 
 // Work counters for persistent kernels: a ring in the code object's own global memory (one copy per device), so launches
 // need no allocation.  Each launch takes the next slot of its device's ring, zeroes it on its stream and leaves an event
@@ -485,12 +487,61 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
         // Wave budget per CU (256 CUs, 32 wave slots, 160 KiB of LDS each): the LDS-table wavefronts hold a 32 KiB table
         // (+ 1 KiB duplicate test in the masked / bulk forms); a global-table wavefront holds the duplicate test (1 KiB)
         // and the slot filter (2 KiB, or 4 KiB with tag classes).  SNAPPY_HIP_GT_WAVES overrides the TOTAL of both kinds.
+        uint32_t* counter = static_cast<uint32_t*>(d_scratch);
+        uint32_t* tables = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_scratch) + 256);
+        HIP_TRY(hipMemsetAsync(counter, 0, 32, st));   // [0] next block, [4] blocks compressed by LDS-table workgroups
+        auto launch_global = [&](uint32_t g) {
+            if (k1_filter == 2)
+                launch_k1_global_class_filtered(g, st, w, block_size, slot_stride, tables, counter);
+            else if (k1_filter)
+                SNAPPY_K1_DISPATCH_FILTERED(k1_ahead, k1_masked, g, st, w, block_size, slot_stride, tables, counter);
+            else
+                SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, w, block_size, slot_stride, tables, counter);
+        };
+        const uint32_t g_wave_bytes = ((k1_masked ? 1u : 0u) + (k1_filter == 2 ? 4u : (k1_filter ? 2u : 0u))) << 10;
+        const int pair_req = env_int("SNAPPY_HIP_PAIR_PER_CU", env_int("SNAPPY_HIP_LDS_WAVES", -1) >= 0 ? 0 : kDefaultPairPerCu);
+        if (pair_req > 0) {
+            // Default: workgroups of TWO wavefronts sharing one u16 table in LDS (compress_blocks_pair_kernel), sized by the
+            // block length -- 2 x table_entries_for(block_size) bytes + 4 KiB of scratch + the token -- so small block sizes
+            // get more of them per CU (reference: dpu_compress.c:472-476 sizes its table to the tasklet's memory).  What is
+            // left of the CU's LDS and wave slots goes to global-table wavefronts on the same work counter.
+            const uint32_t pair_lds = snappy_hip::pair_lds_bytes(block_size);
+            const uint32_t fit = std::min<uint32_t>(kWaveSlotsPerCu / snappy_hip::kPairWaves, kLdsPerCu / ((pair_lds + 1023u) & ~1023u));
+            const uint32_t pair_per_cu = std::min<uint32_t>((uint32_t)pair_req, fit);
+            const uint32_t pair_wgs = (uint32_t)std::min<uint64_t>(nb, (uint64_t)pair_per_cu * kCus);
+            const uint32_t lds_left = kLdsPerCu - pair_per_cu * ((pair_lds + 1023u) & ~1023u);
+            uint32_t g_per_cu = kWaveSlotsPerCu - snappy_hip::kPairWaves * pair_per_cu;
+            if (g_wave_bytes) g_per_cu = std::min(g_per_cu, lds_left / g_wave_bytes);
+            uint32_t g_waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", (int)(g_per_cu * kCus));
+            if (g_waves > kGlobalTableWaves) g_waves = kGlobalTableWaves;
+            if (nb <= pair_wgs) g_waves = 0;                      // every block gets a workgroup of its own at once
+            const uint32_t g = (uint32_t)std::min<uint64_t>(nb, g_waves);
+            if (g) {
+                CoRunResources* cr = nullptr;
+                if (int rc = corun_resources(&cr)) return rc;
+                HIP_TRY(hipEventRecord(cr->ev_begin, st));                 // after the counter memset and all prior work
+                HIP_TRY(hipStreamWaitEvent(cr->helper, cr->ev_begin, 0));
+                hipLaunchKernelGGL(snappy_hip::compress_blocks_pair_kernel, dim3(pair_wgs), dim3(64 * snappy_hip::kPairWaves), pair_lds,
+                                   cr->helper, w, block_size, slot_stride, counter);
+                HIP_TRY(hipEventRecord(cr->ev_end, cr->helper));
+                if (const int head_start = env_int("SNAPPY_HIP_LDS_HEAD_START", kDefaultLdsHeadStart))   // x 3.4 us
+                    hipLaunchKernelGGL(snappy_hip::delay_kernel, dim3(1), dim3(64), 0, st, (uint32_t)head_start);
+                launch_global(g);
+                HIP_TRY(hipStreamWaitEvent(st, cr->ev_end, 0));            // the caller's stream resumes when both are done
+            } else {
+                hipLaunchKernelGGL(snappy_hip::compress_blocks_pair_kernel, dim3(pair_wgs), dim3(64 * snappy_hip::kPairWaves), pair_lds,
+                                   st, w, block_size, slot_stride, counter);
+            }
+            HIP_TRY(hipGetLastError());
+            return SNAPPY_HIP_OK;
+        }
+        // ---- round 1's hybrid (SNAPPY_HIP_PAIR_PER_CU=0 or an explicit SNAPPY_HIP_LDS_WAVES): one-wavefront LDS-table kernel ----
         uint32_t waves = kGlobalTableWaves;
         {
             const uint32_t lds_req = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", kDefaultLdsWaves);
             const uint32_t lds_per_cu = (lds_req + 255u) / 256u;
             const uint32_t lds_wave_kib = 32u + (k1_masked_lds ? 1u : 0u);
-            const uint32_t g_wave_kib = (k1_masked ? 1u : 0u) + (k1_filter == 2 ? 4u : (k1_filter ? 2u : 0u));
+            const uint32_t g_wave_kib = g_wave_bytes >> 10;
             uint32_t g_per_cu = 32u > lds_per_cu ? 32u - lds_per_cu : 0u;
             if (g_wave_kib && lds_per_cu * lds_wave_kib < 160u) {
                 const uint32_t fit = (160u - lds_per_cu * lds_wave_kib) / g_wave_kib;
@@ -500,11 +551,6 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
         }
         waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", (int)waves);
         if (waves > kGlobalTableWaves) waves = kGlobalTableWaves;
-        uint32_t* counter = static_cast<uint32_t*>(d_scratch);
-        uint32_t* tables = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_scratch) + 256);
-        HIP_TRY(hipMemsetAsync(counter, 0, 32, st));   // [0] next block, [4] blocks compressed by the LDS-table form
-        // Hybrid launch: SNAPPY_HIP_LDS_WAVES workgroups of the LDS-table kernel run concurrently on a helper stream
-        // (5 fit per CU by LDS); both kernels draw blocks from the same counter, so the split balances itself.
         uint32_t lds_waves = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", kDefaultLdsWaves);
         if (nb < (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096)) lds_waves = 0;                                  // small inputs: one kernel is enough
         if (lds_waves > waves / 2) lds_waves = waves / 2;
@@ -520,20 +566,10 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
             HIP_TRY(hipEventRecord(ev_end, helper));
             if (const int head_start = env_int("SNAPPY_HIP_LDS_HEAD_START", kDefaultLdsHeadStart))   // x 3.4 us
                 hipLaunchKernelGGL(snappy_hip::delay_kernel, dim3(1), dim3(64), 0, st, (uint32_t)head_start);
-            if (k1_filter == 2)
-                launch_k1_global_class_filtered(g, st, w, block_size, slot_stride, tables, counter);
-            else if (k1_filter)
-                SNAPPY_K1_DISPATCH_FILTERED(k1_ahead, k1_masked, g, st, w, block_size, slot_stride, tables, counter);
-            else
-                SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, w, block_size, slot_stride, tables, counter);
+            launch_global(g);
             HIP_TRY(hipStreamWaitEvent(st, ev_end, 0));                // the caller's stream resumes when both are done
         } else {
-            if (k1_filter == 2)
-                launch_k1_global_class_filtered(g, st, w, block_size, slot_stride, tables, counter);
-            else if (k1_filter)
-                SNAPPY_K1_DISPATCH_FILTERED(k1_ahead, k1_masked, g, st, w, block_size, slot_stride, tables, counter);
-            else
-                SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, w, block_size, slot_stride, tables, counter);
+            launch_global(g);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1545,5 +1581,16 @@ snappy_status snappy_decompress_gpu(struct host_buffer_context* input, struct ho
         return SNAPPY_INVALID_INPUT;
     }
 }
+
+#ifdef SNAPPY_PAIR_PROBE
+int snappy_hip_debug_pair_prof(unsigned long long* out, int reset)
+{
+    if (reset) {
+        unsigned long long z[16] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(snappy_hip::g_pair_prof), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(snappy_hip::g_pair_prof), 16 * sizeof(unsigned long long));
+}
+#endif
 
 }  // extern "C"

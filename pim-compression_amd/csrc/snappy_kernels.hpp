@@ -1511,6 +1511,10 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
     }
 }
 
+}  // namespace snappy_hip
+#include "snappy_k1_pair.hpp"
+namespace snappy_hip {
+
 // ---------------------------------------------------------------------------
 // K1, lane-per-block form: every LANE owns one Snappy block (64 blocks per wavefront) and runs the
 // sequential parse as ordinary SIMT code -- all VALU, no wave-uniform scalar chain, so one

@@ -163,9 +163,33 @@ void launch(uint32_t grid, uint32_t block, const std::function<void()>& body)
             g_waves[t >> 6].active++;
         }
         int remaining = (int)block;
+        // EMU_SHUFFLE=<seed>: run the fibers of a pass in a random order (and whole wavefronts in bursts), so that the
+        // wavefronts of a workgroup interleave differently from run to run -- a stress for code whose wavefronts talk to
+        // each other through LDS (the two-wavefront K1); the default order is deterministic round-robin
+        static const char* shuffle_env = getenv("EMU_SHUFFLE");
+        static uint64_t rng_state = shuffle_env ? (uint64_t)strtoull(shuffle_env, nullptr, 10) * 0x9e3779b97f4a7c15ull + 1 : 0;
+        std::vector<uint32_t> order(block);
+        for (uint32_t t = 0; t < block; ++t) order[t] = t;
         while (remaining > 0) {
             int progressed = 0;
-            for (uint32_t t = 0; t < block; ++t) {
+            bool burst = false;
+            if (shuffle_env) {
+                auto next = [&]() {
+                    rng_state ^= rng_state << 13;
+                    rng_state ^= rng_state >> 7;
+                    rng_state ^= rng_state << 17;
+                    return rng_state;
+                };
+                for (uint32_t t = 0; t < block; ++t) order[t] = t;
+                for (uint32_t i = block; i > 1; --i) std::swap(order[i - 1], order[next() % i]);
+                if (block > 64 && (next() & 3) == 0) {           // a burst: one wavefront alone for this pass
+                    burst = true;
+                    const uint32_t wsel = (uint32_t)(next() % ((block + 63) / 64));
+                    for (uint32_t i = 0; i < block; ++i) order[i] = wsel * 64 + (i & 63) < block ? wsel * 64 + (i & 63) : i;
+                }
+            }
+            for (uint32_t ti = 0; ti < block; ++ti) {
+                const uint32_t t = order[ti];
                 Fiber& f = g_fibers[t];
                 if (f.done) continue;
                 g_cur = (int)t;
@@ -173,7 +197,7 @@ void launch(uint32_t grid, uint32_t block, const std::function<void()>& body)
                 if (f.done) remaining--;
                 progressed++;
             }
-            if (!progressed) break;
+            if (!progressed && !burst) break;
         }
     }
 }
@@ -260,6 +284,11 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
                                                    w, block_size, stride, tables.data(), &counter));
             }
         });
+    } else if (nb && variant == 6) {
+        // two-wavefront workgroups, one shared LDS table per block; a few workgroups pull blocks from the counter
+        const uint32_t grid = nb < 3 ? nb : 3;
+        uint32_t counter[8] = {0};
+        emu::launch(grid, 128, [&] { snappy_hip::compress_blocks_pair_kernel(w, block_size, stride, counter); });
     } else if (nb && variant == 5) {
         const uint32_t grid = nb < 8 ? 1 : 2;
         std::vector<uint32_t> tables((size_t)grid * 4 * 16384, 0xBEEFBEEFu);

@@ -70,6 +70,7 @@ static inline uint32_t emu_mbcnt_hi(uint32_t mask, uint32_t base, uint32_t lane)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __threadfence() ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 
 // single-threaded fibers: a plain read-modify-write is atomic
 static inline uint32_t atomicAdd(uint32_t* p, uint32_t v)

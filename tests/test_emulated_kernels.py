@@ -45,7 +45,7 @@ def test_emulated_long_runs_and_split_copies():
 
 # compress variant = kernel form + 100 * look-ahead code (1 = off, 2 = 4, 3 = 8, 4 = 16, 5 = 64 positions)
 # + 1000 for the masked form, + 2000 for the bulk form, + 10000 for the LDS slot filter (see emu_runtime.cpp)
-@pytest.mark.parametrize("cv,dv", [(1, 0), (3, 1), (4, 0), (5, 1), (103, 1), (303, 1), (403, 1), (101, 1), (301, 0),
+@pytest.mark.parametrize("cv,dv", [(6, 1), (1, 0), (3, 1), (4, 0), (5, 1), (103, 1), (303, 1), (403, 1), (101, 1), (301, 0),
                                    (1403, 1), (1503, 1), (1501, 0), (2403, 1), (2503, 1), (2501, 1),
                                    (10503, 1), (11503, 1), (12503, 1), (10103, 1), (22503, 1)])
 def test_emulated_other_variants(cv, dv):
@@ -120,3 +120,32 @@ def test_emulated_verify_index_accepts_the_chain_and_nothing_else():
     total, got_bs, hdr = oracle.read_header(empty)
     assert emu.verify_index(empty, np.array([hdr], dtype=np.uint64), total, got_bs, hdr)[0] == 0
     assert emu.verify_index(empty + b"x", np.array([hdr], dtype=np.uint64), total, got_bs, hdr)[0] != 0
+
+
+_PAIR_STRESS = """
+import sys
+sys.path.insert(0, sys.argv[1])
+import datagen, emu_lib as emu, oracle_lib as oracle
+from conftest import golden_bytes
+text = golden_bytes("plrabn12.txt")
+cases = [golden_bytes("terror2.txt")[:50000], datagen.text_random_interleave(text, 50000), datagen.records(50000),
+         datagen.low_entropy(30000), datagen.lz_structured(50000, int(sys.argv[2])), datagen.zeros(9000), datagen.periodic(9000, 5)]
+for data in cases:
+    for bs in (32768, 4097):
+        assert emu.compress(data, bs, 6) == oracle.compress(data, bs), (len(data), bs)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_emulated_pair_kernel_under_shuffled_wave_schedules(seed):
+    """The two-wavefront K1 (compress_blocks_pair_kernel): its wavefronts talk through LDS (token, shared hash table), so
+    the emulator runs it with EMU_SHUFFLE -- fibers in random order and whole wavefronts in bursts -- which makes the
+    gather of window k land before, between and after the inserts of window k-1 from run to run."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, EMU_SHUFFLE=str(seed))
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-c", _PAIR_STRESS, here, str(seed)], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]

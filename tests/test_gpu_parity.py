@@ -350,7 +350,9 @@ F0 = {"SNAPPY_HIP_K1_FORM": "0", "SNAPPY_HIP_K1_FILTER": "0", "SNAPPY_HIP_K1_FOR
 TINY_HYBRID = {"SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11", "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"}
 
 
-@pytest.mark.parametrize("env", [{"SNAPPY_HIP_COMPRESS_VARIANT": "1"}, {"SNAPPY_HIP_COMPRESS_VARIANT": "4"},
+@pytest.mark.parametrize("env", [{"SNAPPY_HIP_PAIR_PER_CU": "4", "SNAPPY_HIP_GT_WAVES": "0"}, {"SNAPPY_HIP_PAIR_PER_CU": "3"},
+                                 {"SNAPPY_HIP_PAIR_PER_CU": "1", "SNAPPY_HIP_GT_WAVES": "64"},
+                                 {"SNAPPY_HIP_COMPRESS_VARIANT": "1"}, {"SNAPPY_HIP_COMPRESS_VARIANT": "4"},
                                  {"SNAPPY_HIP_COMPRESS_VARIANT": "4", "SNAPPY_HIP_LANES_PER_BLOCK": "16"},
                                  {"SNAPPY_HIP_COMPRESS_VARIANT": "3", "SNAPPY_HIP_GT_WAVES": "7"},
                                  {"SNAPPY_HIP_COMPRESS_VARIANT": "5"},
