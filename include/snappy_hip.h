@@ -154,6 +154,10 @@ uint32_t snappy_hip_parse_header(const uint8_t *src, uint64_t avail, uint32_t *t
  * of blocks that were compressed by the LDS-table wavefronts of the concurrent launch (statistics only).
  */
 uint64_t snappy_hip_compress_scratch_bytes(void);
+/* Wavefronts per CU whose hash table lives in LDS in a default K1 launch at this block size (the table is sized by the
+ * block size, so small blocks get more of them: reference dpu_compress.c:16, :472-476 sizes its table to the tasklet's
+ * memory the same way).  For the block-size sweep's occupancy column. */
+uint32_t snappy_hip_k1_lds_waves_per_cu(uint32_t block_size);
 int snappy_hip_compress_blocks(const uint8_t *d_in, uint64_t input_len, uint32_t block_size,
                                uint8_t *d_slots, uint32_t slot_stride, uint32_t *d_block_bytes,
                                void *d_scratch, uint64_t scratch_bytes, void *stream);

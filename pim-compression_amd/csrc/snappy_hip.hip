@@ -105,7 +105,7 @@ constexpr int kDefaultK1Form = 2;       // bulk form for the global-table kernel
 constexpr int kDefaultK1Filter = 1;     // with the LDS slot filter
 constexpr int kDefaultLdsHeadStart = 6; // ~20 us for the LDS-table workgroups to be placed before the global-table kernel starts
 constexpr int kDefaultK1FormLds = 2;    // bulk form for the LDS-table kernel
-constexpr int kDefaultLdsWaves = 768;   // 3 LDS-table wavefronts per CU (3 x 33 KiB) beside 20 global-table ones (3 KiB each: filter + duplicate test)
+constexpr int kDefaultLdsWaves = 768;   // block sizes above 8 KiB: 3 LDS-table wavefronts per CU (3 x 33 KiB) beside 20 global-table ones (3 KiB each: filter + duplicate test)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 constexpr uint32_t kCus = 256, kLdsPerCu = 160u << 10, kWaveSlotsPerCu = 32;
 constexpr int kDefaultPairPerCu = 0;    // two-wavefront LDS-table workgroups per CU beside the global-table wavefronts (0 = round 1's one-wavefront LDS-table kernel)
@@ -248,6 +248,18 @@ int env_int(const char* name, int fallback)
     return (v && *v) ? atoi(v) : fallback;
 }
 
+// LDS-table wavefronts per CU of the default K1 launch for a block size (occupancy follows the table the
+// block size needs).  A wavefront holds 2 x table_entries_for(block_size) bytes of table + 1 KiB of duplicate-slot scratch:
+// 33 KiB from -b 16384 up -- there the measured optimum is 3 per CU beside 20 global-table wavefronts -- but 17 KiB at
+// -b 8192, 9 KiB at -b 4096, ...: then as many as the 160 KiB hold (at most 28, leaving wave slots for the global-table
+// form to mop up), since an LDS-table wavefront costs no table traffic at all.
+uint32_t default_lds_waves_per_cu(uint32_t block_size)
+{
+    const uint32_t per_wave = snappy_hip::lds_table_kernel_lds_bytes(block_size, true);
+    if (per_wave > (24u << 10)) return kDefaultLdsWaves / 256;
+    return std::min<uint32_t>(28u, (160u << 10) / per_wave);
+}
+
 // Number of shards the drop-in pair splits a file into: SNAPPY_HIP_NUM_GPUS (default: every visible device).
 // SNAPPY_HIP_OVERSUBSCRIBE=1 (test hook) allows more shards than devices; shard g then runs on device
 // g % device_count, so the sharding and host-side concat paths can be exercised on a one-GPU box.
@@ -324,8 +336,9 @@ template <uint32_t kAhead, int kForm>
 void launch_k1_lds(uint32_t grid, uint32_t lds, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size,
                    uint32_t slot_stride, uint32_t* counter)
 {
-    hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<kAhead, kForm>), dim3(grid), dim3(64), lds, st, w, block_size,
-                       slot_stride, counter);
+    // dynamic LDS = the table for this block size (+ duplicate-slot scratch) + `lds` extra bytes (occupancy ablation)
+    hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<kAhead, kForm>), dim3(grid), dim3(64),
+                       snappy_hip::lds_table_kernel_lds_bytes(block_size, kForm != 0) + lds, st, w, block_size, slot_stride, counter);
 }
 #define SNAPPY_K1_DISPATCH(fn, ahead, form, ...)                \
     do {                                                        \
@@ -416,6 +429,17 @@ uint32_t snappy_hip_parse_header(const uint8_t* src, uint64_t avail, uint32_t* t
     const uint32_t b = get_varint32(src + a, avail - a, block_size);
     if (!b) return 0;
     return a + b;
+}
+
+uint32_t snappy_hip_k1_lds_waves_per_cu(uint32_t block_size)
+{
+    if (!block_size_ok(block_size)) return 0;
+    if (const int pair = env_int("SNAPPY_HIP_PAIR_PER_CU", env_int("SNAPPY_HIP_LDS_WAVES", -1) >= 0 ? 0 : kDefaultPairPerCu)) {
+        const uint32_t pair_lds = (snappy_hip::pair_lds_bytes(block_size) + 1023u) & ~1023u;
+        return snappy_hip::kPairWaves * std::min<uint32_t>({(uint32_t)pair, kWaveSlotsPerCu / snappy_hip::kPairWaves, kLdsPerCu / pair_lds});
+    }
+    const int forced = env_int("SNAPPY_HIP_LDS_WAVES", -1);
+    return forced >= 0 ? ((uint32_t)forced + kCus - 1) / kCus : default_lds_waves_per_cu(block_size);
 }
 
 uint64_t snappy_hip_compress_scratch_bytes(void)
@@ -538,20 +562,19 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
         // ---- round 1's hybrid (SNAPPY_HIP_PAIR_PER_CU=0 or an explicit SNAPPY_HIP_LDS_WAVES): one-wavefront LDS-table kernel ----
         uint32_t waves = kGlobalTableWaves;
         {
-            const uint32_t lds_req = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", kDefaultLdsWaves);
+            const uint32_t lds_req = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", (int)(default_lds_waves_per_cu(block_size) * kCus));
             const uint32_t lds_per_cu = (lds_req + 255u) / 256u;
-            const uint32_t lds_wave_kib = 32u + (k1_masked_lds ? 1u : 0u);
-            const uint32_t g_wave_kib = g_wave_bytes >> 10;
+            const uint32_t lds_wave_bytes = snappy_hip::lds_table_kernel_lds_bytes(block_size, k1_masked_lds != 0);
             uint32_t g_per_cu = 32u > lds_per_cu ? 32u - lds_per_cu : 0u;
-            if (g_wave_kib && lds_per_cu * lds_wave_kib < 160u) {
-                const uint32_t fit = (160u - lds_per_cu * lds_wave_kib) / g_wave_kib;
+            if (g_wave_bytes && lds_per_cu * lds_wave_bytes < kLdsPerCu) {
+                const uint32_t fit = (kLdsPerCu - lds_per_cu * lds_wave_bytes) / g_wave_bytes;
                 g_per_cu = fit < g_per_cu ? fit : g_per_cu;
             }
             waves = lds_req + g_per_cu * 256u;
         }
         waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", (int)waves);
         if (waves > kGlobalTableWaves) waves = kGlobalTableWaves;
-        uint32_t lds_waves = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", kDefaultLdsWaves);
+        uint32_t lds_waves = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", (int)(default_lds_waves_per_cu(block_size) * kCus));
         if (nb < (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096)) lds_waves = 0;                                  // small inputs: one kernel is enough
         if (lds_waves > waves / 2) lds_waves = waves / 2;
         const uint32_t g = (uint32_t)std::min<uint64_t>(nb, waves - lds_waves);

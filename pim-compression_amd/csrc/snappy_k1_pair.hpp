@@ -97,12 +97,7 @@ __device__ __forceinline__ void pair_row_store(pair_rows_t t, uint32_t row, uint
 constexpr uint32_t kPairDone = 1u, kPairPendingInsert = 2u;
 
 // dynamic LDS of one workgroup: [u16 table of table_entries_for(block_size)] [scratch of wave 0] [scratch of wave 1] [token]
-__host__ __device__ inline uint32_t pair_table_entries(uint32_t block_size)
-{
-    uint32_t ts = 256;
-    while (ts < kMaxTableEntries && ts < block_size) ts <<= 1;
-    return ts;
-}
+__host__ __device__ inline uint32_t pair_table_entries(uint32_t block_size) { return lds_table_entries(block_size); }
 __host__ __device__ inline uint32_t pair_lds_bytes(uint32_t block_size)
 {
     return 2u * pair_table_entries(block_size) + kPairWaves * kPairScratchPerWave + kPairTokenBytes;

@@ -1421,6 +1421,18 @@ __device__ __forceinline__ uint32_t batch_container_of(const K1Batch& w, uint32_
     return c;
 }
 
+// u16 table entries the LDS-table kernels reserve for blocks of up to block_size bytes (= table_entries_for(block_size))
+__host__ __device__ inline uint32_t lds_table_entries(uint32_t block_size)
+{
+    uint32_t ts = 256;
+    while (ts < kMaxTableEntries && ts < block_size) ts <<= 1;
+    return ts;
+}
+__host__ __device__ inline uint32_t lds_table_kernel_lds_bytes(uint32_t block_size, bool with_dup_scratch)
+{
+    return 2u * lds_table_entries(block_size) + (with_dup_scratch ? kDupSlots : 16u);
+}
+
 // next_block == nullptr: static grid-stride assignment; otherwise blocks are drawn from the shared atomic counter,
 // which lets this kernel run CONCURRENTLY with compress_blocks_global_table_kernel on the same container (the
 // LDS-table waves fill 5 wave slots per CU with low-latency tables, the global-table waves the other 27).
@@ -1429,8 +1441,13 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const K1B
                                                                        uint32_t* next_block)
 {
     const uint32_t num_blocks = w.first_block[w.count];
-    __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTableEntries];
-    __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kForm ? kDupSlots : 16];
+    // Dynamic LDS, sized by the launch from the block size (lds_table_kernel_lds_bytes): the u16 table of
+    // table_entries_for(block_size) entries -- 512 B for -b 256 ... 32 KiB from -b 16384 up, as the reference sizes its
+    // table to the block (snappy_compress.c:139-146; dpu_compress.c:472-476 to the tasklet's memory) -- then the 1 KiB
+    // duplicate-slot scratch of the masked / bulk forms.  Small block sizes therefore fit many more of these wavefronts per CU.
+    HIP_DYNAMIC_SHARED(uint8_t, lds_dyn)
+    uint16_t* table = reinterpret_cast<uint16_t*>(lds_dyn);
+    uint8_t* dup_scratch = lds_dyn + 2u * lds_table_entries(block_size);
     const uint32_t lane = threadIdx.x;
 #ifndef SNAPPY_EMU
     // The LDS-table wavefronts are few (LDS capacity) but cost no table traffic: let the instruction arbiter prefer them

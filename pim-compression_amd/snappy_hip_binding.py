@@ -78,6 +78,8 @@ def lib():
         L.snappy_hip_compress_blocks_batch.restype = ctypes.c_int
         L.snappy_hip_compress_blocks_batch.argtypes = [vp, u32, u32, u32, vp, u64, vp]
         L.snappy_hip_compress_scratch_bytes.restype = u64
+        L.snappy_hip_k1_lds_waves_per_cu.restype = u32
+        L.snappy_hip_k1_lds_waves_per_cu.argtypes = [u32]
         L.snappy_hip_compact.restype = ctypes.c_int
         L.snappy_hip_compact.argtypes = [vp, u32, vp, u64, u32, vp, vp, vp, vp]
         L.snappy_hip_index_streams.restype = ctypes.c_int
@@ -126,6 +128,10 @@ def shard_block_range(num_blocks_total, shards, shard):
     per = (num_blocks_total + shards - 1) // shards if num_blocks_total else 0
     first = min(num_blocks_total, shard * per)
     return first, min(num_blocks_total, first + per) - first
+
+
+def k1_lds_waves_per_cu(block_size):
+    return int(lib().snappy_hip_k1_lds_waves_per_cu(block_size))
 
 
 def write_header(total_len, block_size):

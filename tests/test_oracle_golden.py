@@ -217,3 +217,44 @@ def test_baseline_standins_shapes_and_oracle_roundtrip():
         stream = oracle.compress(data, 32768, threads=8)
         st, back = oracle.decompress(stream)
         assert st == 0 and back == data
+
+
+def _libsnappy():
+    """Google's Snappy as bundled with pyarrow (the image's offline wheelhouse): a real implementation of the ORIGINAL
+    format (snappy/README.md:9-18) that shares no code with this repository."""
+    pa = pytest.importorskip("pyarrow")
+    if not pa.Codec.is_available("snappy"):
+        pytest.skip("pyarrow was built without snappy")
+    return pa
+
+
+def test_interop_with_a_real_snappy_library_both_directions():
+    """SURVEY 8f rank 4, pinned: the converter's output is decoded by libsnappy (pyarrow) to the plaintext -- for the
+    reference's own golden .snappy files and for oracle streams at other block sizes -- and a stream written BY libsnappy
+    (whose back-references cross our block boundaries freely) is decoded by the converter's reader and re-framed by the
+    dpu_snappy tool into exactly the oracle's bytes."""
+    import importlib.util
+    import os
+    import datagen
+    from conftest import ROOT
+    pa = _libsnappy()
+    spec = importlib.util.spec_from_file_location("to_raw_snappy", os.path.join(ROOT, "tools", "to_raw_snappy.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name in ("alice", "coding", "terror2", "plrabn12", "world192"):
+        txt = golden_bytes(name + ".txt")
+        raw = mod.convert(golden_bytes(name + ".snappy"))
+        assert pa.decompress(raw, decompressed_size=len(txt), codec="snappy").to_pybytes() == txt, name
+    text = golden_bytes("plrabn12.txt")
+    for data in (datagen.text_random_interleave(text, 300_000), datagen.records(200_000), datagen.zeros(100_000),
+                 datagen.lz_structured(150_000, 5), b"", b"a"):
+        for bs in (64, 4096, 32768, 65535):
+            if bs == 64 and len(data) > 50_000:
+                continue
+            raw = mod.convert(oracle.compress(data, bs))
+            got = pa.decompress(raw, decompressed_size=len(data), codec="snappy").to_pybytes() if data else b""
+            assert got == data, (len(data), bs)
+        theirs = pa.compress(data, codec="snappy").to_pybytes()
+        assert mod.decode_raw(theirs) == data
+        if os.path.exists(mod.CLI) and data:
+            assert mod.reframe(theirs, 4096) == oracle.compress(data, 4096)

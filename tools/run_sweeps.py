@@ -3,14 +3,22 @@
 
 Counterpart of the reference's snappy/scripts/asplos21/run_tests.py (which rebuilds the tool per
 (NR_DPUS, NR_TASKLETS) and scrapes its stdout): here the GPU count is a runtime flag (-g), and the
-same stdout lines are scraped.  Three CSVs are written into --out:
+same stdout lines are scraped.  Written into --out:
 
-  speedup.csv     file, bytes, gpus, host_s, gpu_kernel_s, gpu_total_s, speedup_kernel, speedup_total
-                  (host_s = "Host time" of the CPU mode, as run_tests.py's run_dpu_test uses it)
-  breakdown.csv   file, direction, prepare, alloc, load, copy_in, run, copy_out, free, gpus
-                  (column layout of run_breakdown_test, run_tests.py:134,146, with dpus -> gpus)
-  blocksize.csv   file, block_size, compressed_bytes, space_saving, host_compress_s, gpu_run_s
-                  (counterpart of chart_compr_vs_blksize.py's input)
+  in the reference's own layouts (so its chart_breakdown.py / chart_dpu_speedup.py conventions apply unchanged; the
+  device-count column keeps the reference's name `dpus` and holds the number of GPUs):
+    <file>_compression_breakdown.csv, <file>_decompression_breakdown.csv
+                    prepare, alloc, load, copy_in, run, copy_out, free, dpus        (run_tests.py:134, :146)
+    compression_speedup_dpu.csv, decompression_speedup_dpu.csv
+                    version, time, dpus        one `host,1,0` row, then <file>, host time / (GPU run + overheads), count
+                                               (run_tests.py:86-101, :104-119)
+  and, as documented extras:
+    speedup.csv     file, bytes, direction, gpus, host_s, gpu_kernel_s, gpu_total_s, speedup_kernel, speedup_total
+                    (host_s = "Host time" of the CPU mode, as run_tests.py's run_dpu_test uses it)
+    breakdown.csv   file, direction + the eight breakdown columns (last one named gpus): all files in one table
+    blocksize.csv   file, block_size, compressed_bytes, space_saving, host_compress_s, gpu_run_s, lds_waves_per_cu
+                    (counterpart of chart_compr_vs_blksize.py's input; lds_waves_per_cu = wavefronts per CU whose hash
+                    table lives in LDS at that block size, snappy_hip_k1_lds_waves_per_cu)
 
 Usage: python tools/run_sweeps.py --out DIR [--gpus 1,2,4,8] [--files a.txt,b.txt] [--mix-mib 256]
 """
@@ -26,6 +34,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "pim-compression_amd", "host", "dpu_snappy")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+BREAKDOWN_HEADER = ["prepare", "alloc", "load", "copy_in", "run", "copy_out", "free", "dpus"]   # run_tests.py:134
 FIELDS = {"prepare": "Pre-processing time", "alloc": "Alloc time", "load": "Load time", "copy_in": "Copy in time",
           "run": "Host time", "copy_out": "Copy out time", "free": "Free time"}
 
@@ -80,6 +89,8 @@ def main():
         make_mix(mix, args.mix_mib)
         files.append(mix)
 
+    ref_speedup = {"compress": [["version", "time", "dpus"], ["host", "1", "0"]],
+                   "decompress": [["version", "time", "dpus"], ["host", "1", "0"]]}
     with open(os.path.join(args.out, "speedup.csv"), "w", newline="") as fs, \
             open(os.path.join(args.out, "breakdown.csv"), "w", newline="") as fb:
         ws, wb = csv.writer(fs), csv.writer(fb)
@@ -91,6 +102,7 @@ def main():
             comp = os.path.join(work, name + ".snappy")
             host_c = run_cli(["-c", "-i", f, "-o", comp])
             host_d = run_cli(["-i", comp, "-o", os.path.join(work, name + ".host_out")])
+            per_file = {"compress": [BREAKDOWN_HEADER], "decompress": [BREAKDOWN_HEADER]}
             for g in gpus:
                 gc = run_cli(["-d", "-g", str(g), "-c", "-i", f, "-o", comp + ".gpu"])
                 gd = run_cli(["-d", "-g", str(g), "-i", comp, "-o", os.path.join(work, name + ".gpu_out")])
@@ -102,10 +114,22 @@ def main():
                     ws.writerow([name, size, direction, g, f"{host['run']:.6f}", f"{gpu['gpu_kernel_s']:.6f}", f"{total:.6f}",
                                  f"{host['run'] / max(gpu['gpu_kernel_s'], 1e-9):.2f}", f"{host['run'] / max(total, 1e-9):.2f}"])
                     wb.writerow([name, direction] + [f"{gpu[k]:.6f}" for k in FIELDS] + [g])
+                    per_file[direction].append([f"{gpu[k]:.6f}" for k in FIELDS] + [g])
+                    overhead = sum(gpu[k] for k in FIELDS if k != "run")          # run_tests.py:97: host / (dpu + sum(overhead))
+                    ref_speedup[direction].append([name, f"{host['run'] / max(gpu['run'] + overhead, 1e-9):.4f}", g])
+            stem = os.path.splitext(name)[0]
+            for direction, rows in per_file.items():
+                with open(os.path.join(args.out, f"{stem}_{direction}ion_breakdown.csv"), "w", newline="") as fp:
+                    csv.writer(fp).writerows(rows)
+    for direction, rows in ref_speedup.items():
+        with open(os.path.join(args.out, f"{direction}ion_speedup_dpu.csv"), "w", newline="") as fp:
+            csv.writer(fp).writerows(rows)
 
     with open(os.path.join(args.out, "blocksize.csv"), "w", newline="") as fz:
         wz = csv.writer(fz)
-        wz.writerow(["file", "block_size", "compressed_bytes", "space_saving", "host_compress_s", "gpu_run_s"])
+        wz.writerow(["file", "block_size", "compressed_bytes", "space_saving", "host_compress_s", "gpu_run_s", "lds_waves_per_cu"])
+        sys.path.insert(0, os.path.join(ROOT, "pim-compression_amd"))
+        import snappy_hip_binding as shb
         for f in files:
             name = os.path.basename(f)
             for bs in [int(b) for b in args.block_sizes.split(",")]:
@@ -114,7 +138,8 @@ def main():
                 g = run_cli(["-d", "-c", "-b", str(bs), "-i", f, "-o", outp + ".gpu"])
                 if open(outp, "rb").read() != open(outp + ".gpu", "rb").read():
                     raise RuntimeError(f"parity failure on {name} at block size {bs}")
-                wz.writerow([name, bs, h["bytes_out"], f"{h['saving']:.6f}", f"{h['run']:.6f}", f"{g['gpu_kernel_s']:.6f}"])
+                wz.writerow([name, bs, h["bytes_out"], f"{h['saving']:.6f}", f"{h['run']:.6f}", f"{g['gpu_kernel_s']:.6f}",
+                             shb.k1_lds_waves_per_cu(bs)])
     print("wrote", args.out)
 
 
