@@ -97,7 +97,10 @@ int for_each_device(int count, const std::function<int(int)>& fn)
     return 0;
 }
 
-constexpr int kVariantLdsTable = 1, kVariantGlobalTable = 3, kVariantLanePerBlock = 4, kVariantGroup = 5;
+constexpr int kVariantLdsTable = 1, kVariantGlobalTable = 3;
+#ifdef SNAPPY_ABLATION
+constexpr int kVariantLanePerBlock = 4, kVariantGroup = 5;
+#endif
 constexpr int kDefaultDecompressVariant = 1;   // the concurrent LDS+global form (2) measured no faster for K2
 constexpr int kDefaultK1Ahead = 64;     // look-ahead of the global-table form (64 = the whole cursor window)
 constexpr int kDefaultK1AheadLds = 64;  // look-ahead of the LDS-table form
@@ -296,7 +299,12 @@ struct CallerDevice {
     }
 };
 
-// K1 launchers.  SNAPPY_HIP_K1_AHEAD[_LDS] = look-ahead width of the speculative table reads (0 = serial probes only);
+// K1 launchers.  The product library holds ONE K1 pair -- the bulk parse with look-ahead 64, as the global-table kernel
+// behind the LDS slot filter and as the LDS-table kernel -- plus the two-wavefront LDS form.  The other forms of round 1
+// (windowed / masked parses, look-ahead widths, unfiltered and class-filtered tables, lane-per-block and group kernels)
+// are ablation code under csrc/ablation/, compiled only with -DSNAPPY_ABLATION (tools/build_ablation.py).
+#ifdef SNAPPY_ABLATION
+// SNAPPY_HIP_K1_AHEAD[_LDS] = look-ahead width of the speculative table reads (0 = serial probes only);
 // SNAPPY_HIP_K1_FORM[_LDS] = 1 selects the masked form (lane-mask resolution of the probes), 2 the bulk form
 // (per-segment table commit and emission); both need a look-ahead >= 16.
 template <uint32_t kAhead, int kForm>
@@ -336,7 +344,6 @@ template <uint32_t kAhead, int kForm>
 void launch_k1_lds(uint32_t grid, uint32_t lds, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size,
                    uint32_t slot_stride, uint32_t* counter)
 {
-    // dynamic LDS = the table for this block size (+ duplicate-slot scratch) + `lds` extra bytes (occupancy ablation)
     hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<kAhead, kForm>), dim3(grid), dim3(64),
                        snappy_hip::lds_table_kernel_lds_bytes(block_size, kForm != 0) + lds, st, w, block_size, slot_stride, counter);
 }
@@ -356,6 +363,63 @@ void launch_k1_lds(uint32_t grid, uint32_t lds, hipStream_t st, const snappy_hip
             else fn<0, 0>(__VA_ARGS__);                         \
         }                                                       \
     } while (0)
+#endif  // SNAPPY_ABLATION
+
+// What one K1 launch is made of (product: fixed; ablation build: from the SNAPPY_HIP_K1_* environment).
+struct K1Forms {
+    int ahead = kDefaultK1Ahead, ahead_lds = kDefaultK1AheadLds;
+    int form = kDefaultK1Form, form_lds = kDefaultK1FormLds, filter = kDefaultK1Filter;
+    uint32_t extra_lds = 0;
+};
+
+int k1_forms_from_env(K1Forms* f)
+{
+#ifdef SNAPPY_ABLATION
+    f->ahead = env_int("SNAPPY_HIP_K1_AHEAD", kDefaultK1Ahead);
+    f->ahead_lds = env_int("SNAPPY_HIP_K1_AHEAD_LDS", kDefaultK1AheadLds);
+    f->form = env_int("SNAPPY_HIP_K1_FORM", kDefaultK1Form);                 // 0 windowed, 1 masked, 2 bulk
+    f->form_lds = env_int("SNAPPY_HIP_K1_FORM_LDS", kDefaultK1FormLds);
+    f->filter = env_int("SNAPPY_HIP_K1_FILTER", kDefaultK1Filter);           // 0 none, 1 written bit, 2 tag class (bulk, look-ahead 64)
+    f->extra_lds = (uint32_t)env_int("SNAPPY_HIP_EXTRA_LDS", 0);             // occupancy ablation
+#else
+    for (const char* name : {"SNAPPY_HIP_K1_AHEAD", "SNAPPY_HIP_K1_AHEAD_LDS", "SNAPPY_HIP_K1_FORM", "SNAPPY_HIP_K1_FORM_LDS",
+                             "SNAPPY_HIP_K1_FILTER", "SNAPPY_HIP_EXTRA_LDS", "SNAPPY_HIP_LANES_PER_BLOCK", "SNAPPY_HIP_GROUP_WAVES"})
+        if (getenv(name))
+            return fail(SNAPPY_HIP_ERR_ARG, std::string(name) + " selects an ablation kernel; this library was built without them "
+                                                                "(python tools/build_ablation.py builds libsnappy_hip_ablation.so)");
+    (void)f;
+#endif
+    return 0;
+}
+
+void launch_lds_table_kernel(const K1Forms& f, uint32_t grid, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size,
+                             uint32_t slot_stride, uint32_t* counter)
+{
+#ifdef SNAPPY_ABLATION
+    SNAPPY_K1_DISPATCH(launch_k1_lds, f.ahead_lds, f.form_lds, grid, f.extra_lds, st, w, block_size, slot_stride, counter);
+#else
+    hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<64, 2>), dim3(grid), dim3(64),
+                       snappy_hip::lds_table_kernel_lds_bytes(block_size, true), st, w, block_size, slot_stride, counter);
+    (void)f;
+#endif
+}
+
+void launch_global_table_kernel(const K1Forms& f, uint32_t grid, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size,
+                                uint32_t slot_stride, uint32_t* tables, uint32_t* counter)
+{
+#ifdef SNAPPY_ABLATION
+    if (f.filter == 2)
+        launch_k1_global_class_filtered(grid, st, w, block_size, slot_stride, tables, counter);
+    else if (f.filter)
+        SNAPPY_K1_DISPATCH_FILTERED(f.ahead, f.form, grid, st, w, block_size, slot_stride, tables, counter);
+    else
+        SNAPPY_K1_DISPATCH(launch_k1_global, f.ahead, f.form, grid, st, w, block_size, slot_stride, tables, counter);
+#else
+    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 2, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
+                       slot_stride, tables, counter);
+    (void)f;
+#endif
+}
 
 }  // namespace
 
@@ -453,147 +517,144 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
                            uint64_t scratch_bytes, void* stream)
 {
     const uint64_t nb = w.first_block[w.count];
-    const uint8_t* d_in = w.in[0];                     // the single-container ablation kernels (variants 4, 5) use these
-    const uint64_t input_len = w.in_len[0];
-    uint8_t* d_slots = w.slots[0];
-    uint32_t* d_block_bytes = w.block_bytes[0];
-    // SNAPPY_HIP_COMPRESS_VARIANT (ablations): 3 = windowed parse, hash tables in the caller's global scratch,
-    // 32 waves/CU (default); 1 = LDS hash table, 4-5 waves/CU (also the path taken when no scratch is given);
-    // 4 = lane-per-block SIMT experiment; 5 = four blocks per wavefront (16-lane groups).  SNAPPY_HIP_EXTRA_LDS adds dynamic LDS per workgroup (occupancy ablation).
+    // SNAPPY_HIP_COMPRESS_VARIANT: 3 = the concurrent launch below (default); 1 = the LDS-table kernel alone (also the path
+    // taken when no scratch is given); ablation builds only: 4 = lane-per-block SIMT experiment, 5 = four blocks per wavefront.
     int variant = env_int("SNAPPY_HIP_COMPRESS_VARIANT", kVariantGlobalTable);
     if (variant == kVariantGlobalTable &&
         (!d_scratch || scratch_bytes < snappy_hip_compress_scratch_bytes() || ((uintptr_t)d_scratch & 255)))
         variant = kVariantLdsTable;   // no scratch: LDS-table kernel (still on the GPU)
-    if ((variant == kVariantGroup || variant == kVariantLanePerBlock) && w.count != 1)
-        return fail(SNAPPY_HIP_ERR_ARG, "the lane-per-block and group ablation kernels take one container per launch");
-    const uint32_t lds = (uint32_t)env_int("SNAPPY_HIP_EXTRA_LDS", 0);
-    const int k1_ahead = env_int("SNAPPY_HIP_K1_AHEAD", kDefaultK1Ahead);
-    const int k1_ahead_lds = env_int("SNAPPY_HIP_K1_AHEAD_LDS", kDefaultK1AheadLds);
-    const int k1_masked = env_int("SNAPPY_HIP_K1_FORM", kDefaultK1Form);          // 0 windowed, 1 masked, 2 bulk
-    const int k1_masked_lds = env_int("SNAPPY_HIP_K1_FORM_LDS", kDefaultK1FormLds);
-    const int k1_filter = env_int("SNAPPY_HIP_K1_FILTER", kDefaultK1Filter);   // 0 none, 1 written bit, 2 tag class (bulk, look-ahead 64)
-    const dim3 grid((uint32_t)nb), block(64);
+    K1Forms forms;
+    if (int rc = k1_forms_from_env(&forms)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (variant == kVariantGroup) {
-        // ablation: 4 blocks per wavefront (16-lane groups); its tables are allocated lazily by the library
-        static thread_local uint32_t* group_tables = nullptr;
-        static thread_local uint64_t group_table_slots = 0;
-        const uint32_t waves = (uint32_t)env_int("SNAPPY_HIP_GROUP_WAVES", kGlobalTableWaves);
-        const uint64_t want_groups = std::min<uint64_t>((uint64_t)waves * 4, (nb + 3) / 4 * 4);
-        const uint32_t g = (uint32_t)((want_groups + 3) / 4);
-        if (group_table_slots < (uint64_t)g * 4) {
-            if (group_tables) (void)hipFree(group_tables);
-            group_tables = nullptr;
-            HIP_TRY(hipMalloc((void**)&group_tables, (size_t)g * 4 * snappy_hip::kMaxTableEntries * sizeof(uint32_t)));
-            group_table_slots = (uint64_t)g * 4;
-        }
-        static thread_local uint32_t* group_counter = nullptr;
-        if (!group_counter) HIP_TRY(hipMalloc((void**)&group_counter, 256));
-        HIP_TRY(hipMemsetAsync(group_counter, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(snappy_hip::compress_blocks_group_kernel, dim3(g), block, 0, st, d_in, input_len, block_size,
-                           d_slots, slot_stride, d_block_bytes, (uint32_t)nb, group_tables, group_counter);
-    } else if (variant == kVariantLanePerBlock) {
-        static thread_local uint16_t* lane_tables = nullptr;
-        static thread_local uint64_t lane_tables_blocks = 0;
-        if (lane_tables_blocks < nb) {
-            if (lane_tables) (void)hipFree(lane_tables);
-            lane_tables = nullptr;
-            HIP_TRY(hipMalloc((void**)&lane_tables, (size_t)nb * snappy_hip::kMaxTableEntries * sizeof(uint16_t)));
-            lane_tables_blocks = nb;
-        }
-        const uint32_t rep = (uint32_t)env_int("SNAPPY_HIP_LANES_PER_BLOCK", 1);
-        hipLaunchKernelGGL(snappy_hip::compress_blocks_lane_kernel, dim3((uint32_t)((nb * rep + 63) / 64)), block, 0, st, d_in,
-                           input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, lane_tables, rep);
-    } else if (variant == kVariantLdsTable) {
-        SNAPPY_K1_DISPATCH(launch_k1_lds, k1_ahead_lds, k1_masked_lds, (uint32_t)nb, lds, st, w, block_size, slot_stride, (uint32_t*)nullptr);
-    } else {
-        // persistent grid, blocks handed out by an atomic counter kept in the first bytes of the scratch
-        // Wave budget per CU (256 CUs, 32 wave slots, 160 KiB of LDS each): the LDS-table wavefronts hold a 32 KiB table
-        // (+ 1 KiB duplicate test in the masked / bulk forms); a global-table wavefront holds the duplicate test (1 KiB)
-        // and the slot filter (2 KiB, or 4 KiB with tag classes).  SNAPPY_HIP_GT_WAVES overrides the TOTAL of both kinds.
-        uint32_t* counter = static_cast<uint32_t*>(d_scratch);
-        uint32_t* tables = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_scratch) + 256);
-        HIP_TRY(hipMemsetAsync(counter, 0, 32, st));   // [0] next block, [4] blocks compressed by LDS-table workgroups
-        auto launch_global = [&](uint32_t g) {
-            if (k1_filter == 2)
-                launch_k1_global_class_filtered(g, st, w, block_size, slot_stride, tables, counter);
-            else if (k1_filter)
-                SNAPPY_K1_DISPATCH_FILTERED(k1_ahead, k1_masked, g, st, w, block_size, slot_stride, tables, counter);
-            else
-                SNAPPY_K1_DISPATCH(launch_k1_global, k1_ahead, k1_masked, g, st, w, block_size, slot_stride, tables, counter);
-        };
-        const uint32_t g_wave_bytes = ((k1_masked ? 1u : 0u) + (k1_filter == 2 ? 4u : (k1_filter ? 2u : 0u))) << 10;
-        const int pair_req = env_int("SNAPPY_HIP_PAIR_PER_CU", env_int("SNAPPY_HIP_LDS_WAVES", -1) >= 0 ? 0 : kDefaultPairPerCu);
-        if (pair_req > 0) {
-            // Default: workgroups of TWO wavefronts sharing one u16 table in LDS (compress_blocks_pair_kernel), sized by the
-            // block length -- 2 x table_entries_for(block_size) bytes + 4 KiB of scratch + the token -- so small block sizes
-            // get more of them per CU (reference: dpu_compress.c:472-476 sizes its table to the tasklet's memory).  What is
-            // left of the CU's LDS and wave slots goes to global-table wavefronts on the same work counter.
-            const uint32_t pair_lds = snappy_hip::pair_lds_bytes(block_size);
-            const uint32_t fit = std::min<uint32_t>(kWaveSlotsPerCu / snappy_hip::kPairWaves, kLdsPerCu / ((pair_lds + 1023u) & ~1023u));
-            const uint32_t pair_per_cu = std::min<uint32_t>((uint32_t)pair_req, fit);
-            const uint32_t pair_wgs = (uint32_t)std::min<uint64_t>(nb, (uint64_t)pair_per_cu * kCus);
-            const uint32_t lds_left = kLdsPerCu - pair_per_cu * ((pair_lds + 1023u) & ~1023u);
-            uint32_t g_per_cu = kWaveSlotsPerCu - snappy_hip::kPairWaves * pair_per_cu;
-            if (g_wave_bytes) g_per_cu = std::min(g_per_cu, lds_left / g_wave_bytes);
-            uint32_t g_waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", (int)(g_per_cu * kCus));
-            if (g_waves > kGlobalTableWaves) g_waves = kGlobalTableWaves;
-            if (nb <= pair_wgs) g_waves = 0;                      // every block gets a workgroup of its own at once
-            const uint32_t g = (uint32_t)std::min<uint64_t>(nb, g_waves);
-            if (g) {
-                CoRunResources* cr = nullptr;
-                if (int rc = corun_resources(&cr)) return rc;
-                HIP_TRY(hipEventRecord(cr->ev_begin, st));                 // after the counter memset and all prior work
-                HIP_TRY(hipStreamWaitEvent(cr->helper, cr->ev_begin, 0));
-                hipLaunchKernelGGL(snappy_hip::compress_blocks_pair_kernel, dim3(pair_wgs), dim3(64 * snappy_hip::kPairWaves), pair_lds,
-                                   cr->helper, w, block_size, slot_stride, counter);
-                HIP_TRY(hipEventRecord(cr->ev_end, cr->helper));
-                if (const int head_start = env_int("SNAPPY_HIP_LDS_HEAD_START", kDefaultLdsHeadStart))   // x 3.4 us
-                    hipLaunchKernelGGL(snappy_hip::delay_kernel, dim3(1), dim3(64), 0, st, (uint32_t)head_start);
-                launch_global(g);
-                HIP_TRY(hipStreamWaitEvent(st, cr->ev_end, 0));            // the caller's stream resumes when both are done
-            } else {
-                hipLaunchKernelGGL(snappy_hip::compress_blocks_pair_kernel, dim3(pair_wgs), dim3(64 * snappy_hip::kPairWaves), pair_lds,
-                                   st, w, block_size, slot_stride, counter);
+#ifdef SNAPPY_ABLATION
+    if (variant == kVariantGroup || variant == kVariantLanePerBlock) {
+        if (w.count != 1) return fail(SNAPPY_HIP_ERR_ARG, "the lane-per-block and group ablation kernels take one container per launch");
+        const uint8_t* d_in = w.in[0];
+        const uint64_t input_len = w.in_len[0];
+        uint8_t* d_slots = w.slots[0];
+        uint32_t* d_block_bytes = w.block_bytes[0];
+        const dim3 block(64);
+        if (variant == kVariantGroup) {
+            // 4 blocks per wavefront (16-lane groups); its tables are allocated lazily by the library
+            static thread_local uint32_t* group_tables = nullptr;
+            static thread_local uint64_t group_table_slots = 0;
+            const uint32_t waves = (uint32_t)env_int("SNAPPY_HIP_GROUP_WAVES", kGlobalTableWaves);
+            const uint64_t want_groups = std::min<uint64_t>((uint64_t)waves * 4, (nb + 3) / 4 * 4);
+            const uint32_t g = (uint32_t)((want_groups + 3) / 4);
+            if (group_table_slots < (uint64_t)g * 4) {
+                if (group_tables) (void)hipFree(group_tables);
+                group_tables = nullptr;
+                HIP_TRY(hipMalloc((void**)&group_tables, (size_t)g * 4 * snappy_hip::kMaxTableEntries * sizeof(uint32_t)));
+                group_table_slots = (uint64_t)g * 4;
             }
-            HIP_TRY(hipGetLastError());
-            return SNAPPY_HIP_OK;
-        }
-        // ---- round 1's hybrid (SNAPPY_HIP_PAIR_PER_CU=0 or an explicit SNAPPY_HIP_LDS_WAVES): one-wavefront LDS-table kernel ----
-        uint32_t waves = kGlobalTableWaves;
-        {
-            const uint32_t lds_req = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", (int)(default_lds_waves_per_cu(block_size) * kCus));
-            const uint32_t lds_per_cu = (lds_req + 255u) / 256u;
-            const uint32_t lds_wave_bytes = snappy_hip::lds_table_kernel_lds_bytes(block_size, k1_masked_lds != 0);
-            uint32_t g_per_cu = 32u > lds_per_cu ? 32u - lds_per_cu : 0u;
-            if (g_wave_bytes && lds_per_cu * lds_wave_bytes < kLdsPerCu) {
-                const uint32_t fit = (kLdsPerCu - lds_per_cu * lds_wave_bytes) / g_wave_bytes;
-                g_per_cu = fit < g_per_cu ? fit : g_per_cu;
-            }
-            waves = lds_req + g_per_cu * 256u;
-        }
-        waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", (int)waves);
-        if (waves > kGlobalTableWaves) waves = kGlobalTableWaves;
-        uint32_t lds_waves = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", (int)(default_lds_waves_per_cu(block_size) * kCus));
-        if (nb < (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096)) lds_waves = 0;                                  // small inputs: one kernel is enough
-        if (lds_waves > waves / 2) lds_waves = waves / 2;
-        const uint32_t g = (uint32_t)std::min<uint64_t>(nb, waves - lds_waves);
-        if (lds_waves) {
-            CoRunResources* cr = nullptr;
-            if (int rc = corun_resources(&cr)) return rc;
-            hipStream_t helper = cr->helper;
-            hipEvent_t ev_begin = cr->ev_begin, ev_end = cr->ev_end;
-            HIP_TRY(hipEventRecord(ev_begin, st));                     // after the counter memset and all prior work
-            HIP_TRY(hipStreamWaitEvent(helper, ev_begin, 0));
-            SNAPPY_K1_DISPATCH(launch_k1_lds, k1_ahead_lds, k1_masked_lds, lds_waves, 0u, helper, w, block_size, slot_stride, counter);
-            HIP_TRY(hipEventRecord(ev_end, helper));
-            if (const int head_start = env_int("SNAPPY_HIP_LDS_HEAD_START", kDefaultLdsHeadStart))   // x 3.4 us
-                hipLaunchKernelGGL(snappy_hip::delay_kernel, dim3(1), dim3(64), 0, st, (uint32_t)head_start);
-            launch_global(g);
-            HIP_TRY(hipStreamWaitEvent(st, ev_end, 0));                // the caller's stream resumes when both are done
+            static thread_local uint32_t* group_counter = nullptr;
+            if (!group_counter) HIP_TRY(hipMalloc((void**)&group_counter, 256));
+            HIP_TRY(hipMemsetAsync(group_counter, 0, sizeof(uint32_t), st));
+            hipLaunchKernelGGL(snappy_hip::compress_blocks_group_kernel, dim3(g), block, 0, st, d_in, input_len, block_size,
+                               d_slots, slot_stride, d_block_bytes, (uint32_t)nb, group_tables, group_counter);
         } else {
-            launch_global(g);
+            static thread_local uint16_t* lane_tables = nullptr;
+            static thread_local uint64_t lane_tables_blocks = 0;
+            if (lane_tables_blocks < nb) {
+                if (lane_tables) (void)hipFree(lane_tables);
+                lane_tables = nullptr;
+                HIP_TRY(hipMalloc((void**)&lane_tables, (size_t)nb * snappy_hip::kMaxTableEntries * sizeof(uint16_t)));
+                lane_tables_blocks = nb;
+            }
+            const uint32_t rep = (uint32_t)env_int("SNAPPY_HIP_LANES_PER_BLOCK", 1);
+            hipLaunchKernelGGL(snappy_hip::compress_blocks_lane_kernel, dim3((uint32_t)((nb * rep + 63) / 64)), block, 0, st, d_in,
+                               input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, lane_tables, rep);
         }
+        HIP_TRY(hipGetLastError());
+        return SNAPPY_HIP_OK;
+    }
+#endif
+    if (variant != kVariantGlobalTable && variant != kVariantLdsTable)
+        return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_COMPRESS_VARIANT: this build has variants 1 and 3 (ablation kernels: tools/build_ablation.py)");
+    if (variant == kVariantLdsTable) {
+        launch_lds_table_kernel(forms, (uint32_t)nb, st, w, block_size, slot_stride, (uint32_t*)nullptr);
+        HIP_TRY(hipGetLastError());
+        return SNAPPY_HIP_OK;
+    }
+
+    // ---- the default: persistent grids, blocks handed out by an atomic counter kept in the first bytes of the scratch ----
+    // Wave budget per CU (256 CUs, 32 wave slots, 160 KiB of LDS each): a global-table wavefront holds the duplicate test
+    // (1 KiB) and the slot filter (2 KiB) in LDS and its tagged table in the scratch; the wavefronts whose table lives in
+    // LDS are sized by the block length.  SNAPPY_HIP_GT_WAVES overrides the number of global-table wavefronts
+    // (with SNAPPY_HIP_LDS_WAVES / round 1's launch: the TOTAL of both kinds).
+    uint32_t* counter = static_cast<uint32_t*>(d_scratch);
+    uint32_t* tables = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_scratch) + 256);
+    HIP_TRY(hipMemsetAsync(counter, 0, 32, st));   // [0] next block, [4] blocks compressed by wavefronts with an LDS table
+    const uint32_t g_wave_bytes = ((forms.form ? 1u : 0u) + (forms.filter == 2 ? 4u : (forms.filter ? 2u : 0u))) << 10;
+    // fork / join around the caller's stream: `lds_launch` goes to the helper stream, the global-table kernel stays on `st`
+    auto co_run = [&](uint32_t g, const std::function<void(hipStream_t)>& lds_launch) -> int {
+        CoRunResources* cr = nullptr;
+        if (int rc = corun_resources(&cr)) return rc;
+        HIP_TRY(hipEventRecord(cr->ev_begin, st));                     // after the counter memset and all prior work
+        HIP_TRY(hipStreamWaitEvent(cr->helper, cr->ev_begin, 0));
+        lds_launch(cr->helper);
+        HIP_TRY(hipEventRecord(cr->ev_end, cr->helper));
+        // a head start for the LDS-heavy workgroups: placed first, the 3 KiB allocations cannot fragment the LDS under them
+        if (const int head_start = env_int("SNAPPY_HIP_LDS_HEAD_START", kDefaultLdsHeadStart))   // x 3.4 us
+            hipLaunchKernelGGL(snappy_hip::delay_kernel, dim3(1), dim3(64), 0, st, (uint32_t)head_start);
+        launch_global_table_kernel(forms, g, st, w, block_size, slot_stride, tables, counter);
+        HIP_TRY(hipStreamWaitEvent(st, cr->ev_end, 0));                // the caller's stream resumes when both are done
+        return 0;
+    };
+    const int pair_req = env_int("SNAPPY_HIP_PAIR_PER_CU", env_int("SNAPPY_HIP_LDS_WAVES", -1) >= 0 ? 0 : kDefaultPairPerCu);
+    if (pair_req > 0) {
+        // Workgroups of TWO wavefronts sharing one u16 table in LDS (compress_blocks_pair_kernel): 2 x table_entries_for(
+        // block_size) bytes + 4 KiB of scratch + the token each.  What is left of the CU's LDS and wave slots goes to
+        // global-table wavefronts on the same work counter.
+        const uint32_t pair_lds = snappy_hip::pair_lds_bytes(block_size);
+        const uint32_t fit = std::min<uint32_t>(kWaveSlotsPerCu / snappy_hip::kPairWaves, kLdsPerCu / ((pair_lds + 1023u) & ~1023u));
+        const uint32_t pair_per_cu = std::min<uint32_t>((uint32_t)pair_req, fit);
+        const uint32_t pair_wgs = (uint32_t)std::min<uint64_t>(nb, (uint64_t)pair_per_cu * kCus);
+        const uint32_t lds_left = kLdsPerCu - pair_per_cu * ((pair_lds + 1023u) & ~1023u);
+        uint32_t g_per_cu = kWaveSlotsPerCu - snappy_hip::kPairWaves * pair_per_cu;
+        if (g_wave_bytes) g_per_cu = std::min(g_per_cu, lds_left / g_wave_bytes);
+        uint32_t g_waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", (int)(g_per_cu * kCus));
+        if (g_waves > kGlobalTableWaves) g_waves = kGlobalTableWaves;
+        if (nb <= pair_wgs) g_waves = 0;                      // every block gets a workgroup of its own at once
+        const uint32_t g = (uint32_t)std::min<uint64_t>(nb, g_waves);
+        auto pair_launch = [&](hipStream_t on) {
+            hipLaunchKernelGGL(snappy_hip::compress_blocks_pair_kernel, dim3(pair_wgs), dim3(64 * snappy_hip::kPairWaves), pair_lds, on, w,
+                               block_size, slot_stride, counter);
+        };
+        if (g) {
+            if (int rc = co_run(g, pair_launch)) return rc;
+        } else {
+            pair_launch(st);
+        }
+        HIP_TRY(hipGetLastError());
+        return SNAPPY_HIP_OK;
+    }
+    // One-wavefront LDS-table workgroups (the default): SNAPPY_HIP_LDS_WAVES of them run concurrently on the helper stream,
+    // default_lds_waves_per_cu(block_size) per CU; both kernels draw blocks from the same counter, so the split balances itself.
+    uint32_t lds_waves = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", (int)(default_lds_waves_per_cu(block_size) * kCus));
+    uint32_t waves;
+    {
+        const uint32_t lds_per_cu = (lds_waves + kCus - 1) / kCus;
+        const uint32_t lds_wave_bytes = snappy_hip::lds_table_kernel_lds_bytes(block_size, forms.form_lds != 0) + forms.extra_lds;
+        uint32_t g_per_cu = kWaveSlotsPerCu > lds_per_cu ? kWaveSlotsPerCu - lds_per_cu : 0u;
+        if (g_wave_bytes && lds_per_cu * lds_wave_bytes < kLdsPerCu)
+            g_per_cu = std::min(g_per_cu, (kLdsPerCu - lds_per_cu * lds_wave_bytes) / g_wave_bytes);
+        waves = lds_waves + g_per_cu * kCus;
+    }
+    waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", (int)waves);
+    if (waves > kGlobalTableWaves) waves = kGlobalTableWaves;
+    if (nb < (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096)) lds_waves = 0;     // small inputs: one kernel is enough
+    if (lds_waves > waves / 2 && lds_waves < waves) {
+        // small block sizes: most wavefronts have their table in LDS; the global-table form only mops up what is left
+    } else if (lds_waves >= waves) {
+        lds_waves = waves / 2;
+    }
+    const uint32_t g = (uint32_t)std::min<uint64_t>(nb, waves - lds_waves);
+    if (lds_waves) {
+        if (int rc = co_run(g, [&](hipStream_t on) { launch_lds_table_kernel(forms, lds_waves, on, w, block_size, slot_stride, counter); }))
+            return rc;
+    } else {
+        launch_global_table_kernel(forms, g, st, w, block_size, slot_stride, tables, counter);
     }
     HIP_TRY(hipGetLastError());
     return SNAPPY_HIP_OK;
@@ -711,23 +772,24 @@ int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, c
     if (!d_stream || !d_block_offsets || !d_out || !d_status) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
     const uint64_t nb = snappy_hip_num_blocks(total_len, block_size);
     if (nb > 0x7fffffffull) return fail(SNAPPY_HIP_ERR_ARG, "too many blocks");
-    // SNAPPY_HIP_DECOMPRESS_VARIANT: 0 = output window in LDS only, 1 (default) = output window in global memory only,
-    // 2 = both forms concurrently (no gain measured for K2, kept as an ablation): SNAPPY_HIP_K2_LDS_WAVES LDS-window wavefronts on a helper stream beside
-    // the global-window ones, all drawing blocks from one counter.
-    const int variant = env_int("SNAPPY_HIP_DECOMPRESS_VARIANT", kDefaultDecompressVariant);
     hipStream_t st = (hipStream_t)stream;
     // every block's status starts as "not decoded": a block the launch never reaches cannot read back as OK
     HIP_TRY(hipMemsetAsync(d_status, 0xff, nb * sizeof(uint32_t), st));
     WorkCounter wc;
     if (int rc = next_work_counter(&wc, st)) return rc;
     uint32_t* counter = wc.ptr;
-    const uint32_t lds_bytes = (block_size + 15u) & ~15u;
     const uint32_t resident = kGlobalTableWaves;
+    const uint32_t k2_cap = (uint32_t)std::max(1, env_int("SNAPPY_HIP_K2_WAVES", (int)resident));   // fewer wavefronts leave slots for a co-running kernel
+#ifdef SNAPPY_ABLATION
+    // SNAPPY_HIP_DECOMPRESS_VARIANT: 0 = output window in LDS only, 1 (default) = output window in global memory only,
+    // 2 = both forms concurrently (no gain measured for K2): SNAPPY_HIP_K2_LDS_WAVES LDS-window wavefronts on a helper stream
+    // beside the global-window ones, all drawing blocks from one counter.
+    const int variant = env_int("SNAPPY_HIP_DECOMPRESS_VARIANT", kDefaultDecompressVariant);
+    const uint32_t lds_bytes = (block_size + 15u) & ~15u;
     uint32_t lds_waves = 0;
     if (variant == 0) lds_waves = (uint32_t)std::min<uint64_t>(nb, resident);
     else if (variant == 2 && nb >= (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096))
         lds_waves = (uint32_t)env_int("SNAPPY_HIP_K2_LDS_WAVES", lds_bytes > 32768 ? 512 : 1024);
-    const uint32_t k2_cap = (uint32_t)std::max(1, env_int("SNAPPY_HIP_K2_WAVES", (int)resident));   // fewer wavefronts leave slots for a co-running kernel
     const uint32_t glob_waves = (variant == 0) ? 0 : (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nb, k2_cap), resident - std::min(lds_waves, resident / 2));
     if (lds_waves && glob_waves) {
         CoRunResources* cr = nullptr;
@@ -745,8 +807,16 @@ int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, c
     } else if (lds_waves) {
         hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, st, d_stream,
                            stream_len, d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb, counter);
-    } else {
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<false>, dim3(glob_waves), dim3(64), 0, st, d_stream, stream_len,
+    } else
+#else
+    if (getenv("SNAPPY_HIP_DECOMPRESS_VARIANT") && env_int("SNAPPY_HIP_DECOMPRESS_VARIANT", kDefaultDecompressVariant) != kDefaultDecompressVariant) {
+        (void)work_counter_launched(wc, st);
+        return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_DECOMPRESS_VARIANT selects an ablation kernel; this library was built without them");
+    }
+#endif
+    {
+        const uint32_t glob = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nb, k2_cap), resident);
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<false>, dim3(glob), dim3(64), 0, st, d_stream, stream_len,
                            d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb, counter);
     }
     const hipError_t launched = hipGetLastError();
@@ -850,12 +920,15 @@ int pipeline_streams(int shard, size_t chunks, PipelineStreams** out)
 // SNAPPY_HIP_PIPELINE_BLOCKS: blocks per pipeline chunk of the drop-in pair (0 = strictly phased copy-in / run /
 // copy-out, the reference's own order).  Default: 4096 blocks -- a K1 launch of one block per resident wavefront, and
 // 128 MiB per copy -- shrinking to a quarter of the shard (not below 2048) so that a 256 MiB file still overlaps.
-uint64_t pipeline_chunk_blocks(uint64_t shard_blocks)
+uint64_t pipeline_chunk_blocks(uint64_t shard_blocks, uint32_t block_size)
 {
     const char* v = getenv("SNAPPY_HIP_PIPELINE_BLOCKS");
     if (v && *v) return atoi(v) > 0 ? (uint64_t)atoi(v) : 0;
+    // the chunk is sized in BYTES (128 MiB, at least 64 MiB): with small blocks a chunk of 4096 blocks would be a 16 MiB
+    // copy and a 0.2 ms launch, and the pipeline would be bound by launches
+    const uint64_t scale = std::max<uint64_t>(1, 32768 / std::max<uint32_t>(block_size, 1));
     const uint64_t quarter = ((shard_blocks + 3) / 4 + 15) & ~15ull;
-    return std::min<uint64_t>(4096, std::max<uint64_t>(2048, quarter));
+    return std::min<uint64_t>(4096 * scale, std::max<uint64_t>(2048 * scale, quarter));
 }
 
 // split `nb` blocks into equal chunks of at most `chunk` blocks, each a multiple of 16 blocks (keeps every chunk's
@@ -987,8 +1060,8 @@ bool walk_chain(DecompressShard& s, uint64_t upto, const uint8_t* buf, uint64_t 
 int warm_up_device()
 {
     hipFuncAttributes fa;
-    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel<0, 0>)));
-    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_lds_table_kernel<0, 0>)));
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel<64, 2, 1>)));
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_lds_table_kernel<64, 2>)));
     HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::gather_slots_kernel)));
     HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel<false>)));
     CoRunResources* cr = nullptr;
@@ -1463,7 +1536,7 @@ static snappy_status compress_gpu_body(struct host_buffer_context* input, struct
     runtime->pre += now_seconds() - t0;
     // One code path: a shard is a list of chunks; SNAPPY_HIP_PIPELINE_BLOCKS=0 (or a small shard) makes it one chunk, which
     // is the strictly phased copy-in / run / copy-out of the reference (snappy_compress.c:547-704).
-    uint64_t chunk_blocks = pipeline_chunk_blocks(per);
+    uint64_t chunk_blocks = pipeline_chunk_blocks(per, block_size);
     if (!chunk_blocks || per <= chunk_blocks) chunk_blocks = std::max<uint64_t>(per, 1);
     return compress_pipelined(input, output, block_size, runtime, sh, gpus, hdr, hdr_len, stride, chunk_blocks);
 }
@@ -1517,7 +1590,7 @@ static snappy_status decompress_gpu_body(struct host_buffer_context* input, stru
     if ((uint64_t)gpus > nb) gpus = (int)nb;
     // A decode launch takes about as long for 2048 blocks as for 8192 (one block per wavefront either way), so the
     // overlapped form pays from three chunks per shard upwards.
-    const uint64_t chunk_blocks = pipeline_chunk_blocks((nb + gpus - 1) / gpus);
+    const uint64_t chunk_blocks = pipeline_chunk_blocks((nb + gpus - 1) / gpus, bs);
     const bool overlapped = chunk_blocks && (nb + gpus - 1) / gpus >= 3 * chunk_blocks;
     if (overlapped && gpus == 1) {
         // one shard: the host walks the size chain chunk by chunk inside the pipeline instead of up front

@@ -260,25 +260,6 @@ struct CursorWindow {
     }
 };
 
-// 12 candidate bytes through the scalar cache: c0 = le32(cand) for the hit test, c1/c2 = the next 8 bytes for
-// the match extension.  Aligned dwords + 64-bit shifts; needs cand + 16 <= block length (true for every
-// candidate: cand < ip <= n - 15).  (Shifting all three eagerly measured 10 % faster than deferring c1/c2.)
-struct CandidateBytes {
-    uint32_t c0, c1, c2;
-    __device__ __forceinline__ void fetch(const uint8_t* __restrict__ base16, uint64_t abs_pos)
-    {
-        const uint32_t* w = static_cast<const uint32_t*>(__builtin_assume_aligned(base16 + (abs_pos & ~3ull), 4));
-        const uint32_t sh = 8 * (uint32_t)(abs_pos & 3);
-        const uint64_t v01 = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-        const uint64_t v12 = (uint64_t)w[1] | ((uint64_t)w[2] << 32);
-        const uint64_t v23 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
-        c0 = (uint32_t)(v01 >> sh);
-        c1 = (uint32_t)(v12 >> sh);
-        c2 = (uint32_t)(v23 >> sh);
-    }
-    __device__ __forceinline__ uint64_t next8() const { return (uint64_t)c1 | ((uint64_t)c2 << 32); }
-};
-
 // LDS pointers keep their address space (ds_* instead of flat_*); the CPU emulator sees plain pointers.
 #ifdef SNAPPY_EMU
 typedef volatile uint8_t* lds_bytes_t;
@@ -298,45 +279,11 @@ __device__ __forceinline__ void lds_and(lds_words_t p, uint32_t v)
 }
 #endif
 
-// Tagged hash table of the windowed form: entry = tag << 16 | position (u32), where the tag is a 16-bit function
-// of the 4 bytes at that position.  The positions stored and returned are exactly the reference's
-// (snappy_compress.c:346-347, :392-397); the tag only lets a probe whose candidate has a DIFFERENT tag -- hence
-// different 4 bytes, a certain miss in the reference's compare (:348, :398) -- skip fetching the candidate bytes.
-// An empty slot reads "position 0" in the reference, so tables are initialised with position 0's own entry.
-// The index is pinned into a VGPR so the access uses SGPR-base + VGPR-offset addressing, and every lane stores
-// the same value to the same address (one write on the wire, no exec-mask save/restore).  uni() sits between the
-// load and the store, so every lane has read before any lane writes.
-struct TaggedGlobalTable {      // u32 entries in the global scratch: tag << 16 | position
-    uint32_t* __restrict__ t;
-    __device__ __forceinline__ void init(uint32_t entries, uint32_t entry_zero, uint32_t lane) const
-    {
-        uint4* q = reinterpret_cast<uint4*>(t);
-        for (uint32_t i = lane; i < entries / 4; i += kWave) q[i] = make_uint4(entry_zero, entry_zero, entry_zero, entry_zero);
-    }
-    // returns the previous entry and stores `entry`
-    __device__ __forceinline__ uint32_t exchange(uint32_t h, uint32_t entry, uint32_t) const
-    {
-        uint32_t hv = h;
-        SNAPPY_PIN(hv);
-        const uint32_t old = uni(t[hv]);
-        t[hv] = entry;
-        __builtin_amdgcn_wave_barrier();
-        return old;
-    }
-    __device__ __forceinline__ void put(uint32_t h, uint32_t entry, uint32_t) const
-    {
-        uint32_t hv = h;
-        SNAPPY_PIN(hv);
-        t[hv] = entry;
-        __builtin_amdgcn_wave_barrier();
-    }
-    // true when the candidate stored in `old` can be skipped without looking at its bytes
-    __device__ __forceinline__ static bool certain_miss(uint32_t old, uint32_t entry) { return ((old ^ entry) >> 16) != 0; }
-    // per-lane (divergent index) accessors for the look-ahead gather
-    __device__ __forceinline__ uint32_t load_lane(uint32_t h, uint32_t = 0) const { return t[h]; }
-    __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const { t[h] = entry; }
-    __device__ __forceinline__ TaggedGlobalTable with_empty(uint32_t) const { return *this; }
-};
+#ifdef SNAPPY_ABLATION
+}  // namespace snappy_hip
+#include "ablation/k1_tables.hpp"
+namespace snappy_hip {
+#endif
 
 // TaggedGlobalTable behind a one-bit-per-slot "written in this block" filter in LDS (2 KiB per wavefront).  Early in a
 // block most slots still hold the initial entry (candidate position 0, :145 + :346), and the speculative gathers of the
@@ -382,67 +329,6 @@ struct FilteredGlobalTable {
         lds_or(written + (h >> 5), 1u << (h & 31u));
     }
     __device__ __forceinline__ FilteredGlobalTable with_empty(uint32_t e) const { return FilteredGlobalTable{t, written, e}; }
-};
-
-// FilteredGlobalTable with two bits per slot (4 KiB of LDS per wavefront): 0 = not written in this block, 1..3 = a class of
-// the 16-bit content tag of the entry the slot holds.  A probe whose own tag falls in a different class cannot match that
-// entry (different tag => different 4 bytes, a certain miss in :348 / :398), so its table line is not read either; the
-// caller gets an entry with the complemented tag, which certain_miss() rejects.  About 60 % of the probes of written
-// slots end here.
-struct ClassFilteredGlobalTable {
-    uint32_t* __restrict__ t;
-    lds_words_t cls;            // kMaxTableEntries / 16 words
-    uint32_t empty;             // tag(position 0) << 16 | 0
-    __device__ __forceinline__ static uint32_t class_of(uint32_t entry)
-    {
-        const uint32_t two = (entry >> 16) & 3u;
-        return 1u + (two < 2u ? two : 2u);
-    }
-    __device__ __forceinline__ void init(uint32_t entries, uint32_t, uint32_t lane) const
-    {
-        for (uint32_t i = lane; i < entries / 16; i += kWave) cls[i] = 0;
-        __builtin_amdgcn_wave_barrier();
-    }
-    __device__ __forceinline__ uint32_t slot_class(uint32_t h) const { return (cls[h >> 4] >> ((h & 15u) * 2u)) & 3u; }
-    __device__ __forceinline__ void set_class(uint32_t h, uint32_t entry) const
-    {
-        const uint32_t sh = (h & 15u) * 2u;
-        lds_and(cls + (h >> 4), ~(3u << sh));
-        lds_or(cls + (h >> 4), class_of(entry) << sh);
-    }
-    // what a probe carrying `probe_entry` needs to know about slot h
-    __device__ __forceinline__ uint32_t load_lane(uint32_t h, uint32_t probe_entry) const
-    {
-        const uint32_t c = slot_class(h);
-        if (c == 0) return empty;
-        if (c != class_of(probe_entry)) return ~probe_entry & 0xffff0000u;     // some other tag: a certain miss
-        return t[h];
-    }
-    __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const
-    {
-        t[h] = entry;
-        set_class(h, entry);
-    }
-    __device__ __forceinline__ uint32_t exchange(uint32_t h, uint32_t entry, uint32_t lane) const
-    {
-        uint32_t hv = h;
-        SNAPPY_PIN(hv);
-        const uint32_t old = uni(load_lane(hv, entry));
-        t[hv] = entry;
-        if (lane == 0) set_class(h, entry);
-        __builtin_amdgcn_wave_barrier();
-        return old;
-    }
-    __device__ __forceinline__ void put(uint32_t h, uint32_t entry, uint32_t lane) const
-    {
-        uint32_t hv = h;
-        SNAPPY_PIN(hv);
-        t[hv] = entry;
-        if (lane == 0) set_class(h, entry);
-        __builtin_amdgcn_wave_barrier();
-    }
-    __device__ __forceinline__ static bool certain_miss(uint32_t old, uint32_t entry) { return ((old ^ entry) >> 16) != 0; }
-    __device__ __forceinline__ ClassFilteredGlobalTable with_empty(uint32_t e) const { return ClassFilteredGlobalTable{t, cls, e}; }
 };
 
 struct LdsTable {               // the reference's own layout: u16 positions, in LDS (no room for tags: 32 KiB per block)
@@ -515,201 +401,11 @@ __device__ __forceinline__ uint32_t emit_literal_windowed(uint8_t* __restrict__ 
     return op + hdr + len;
 }
 
-// Speculative table-entry cache of the windowed form ("look-ahead").  The hash of every position in the cursor window is
-// already in a register, so the table slots the parse MAY probe next are known before it gets there.  When a probe lands on
-// a window lane whose slot has not been read yet, lanes r .. r+kAhead-1 read their slots in ONE gather (`ent`), and the
-// lanes whose tag matches read their 12 candidate bytes in a second (`k0..k2`, `kmask`).  Later probes inside the covered
-// range take entry and candidate bytes from registers: a chain of short matches or a scan run costs two memory round trips
-// per kAhead positions instead of two per probe.  The cached entries are kept equal to the table: every table write
-// (probe inserts, :347/:397, and the post-match insert, :391-392) also overwrites `ent` in the lanes that hash to the
-// written slot, and drops their cached candidate bytes (`kmask`), which belong to the previous occupant.
-// A probe therefore sees exactly the entry the reference's sequential table would hold.
-template <class Table, uint32_t kAhead>
-struct EntryCache {
-    uint32_t ent = 0;                 // per lane: table[h0] as of now, valid for lanes in [.., cov_end)
-    uint32_t k0 = 0, k1 = 0, k2 = 0;  // per lane: 12 bytes at (ent & 0xffff), valid where kmask has the lane's bit
-    unsigned long long kmask = 0;     // wave-uniform
-    uint32_t cov_end = 0;             // wave-uniform: window lanes below this have a valid `ent` (lanes behind ip are dead)
-
-    __device__ __forceinline__ void invalidate()
-    {
-        cov_end = 0;
-        kmask = 0;
-    }
-    // read slots for lanes [r, r+span) of the window (clipped at 64), and candidate bytes where the tag allows a hit
-    __device__ __forceinline__ void gather(const Table& table, const CursorWindow& win, uint32_t r, uint32_t span,
-                                           uint32_t lane)
-    {
-        const bool g = lane >= r && lane < r + span;
-        const uint32_t mine_l = win.e0 | (win.base + lane);
-        if (g) ent = table.load_lane(win.h0, mine_l);
-        const bool worth = g && !Table::certain_miss(ent, mine_l);
-        if (worth) {                                  // every stored position p has p + 16 <= block length
-            const uint8_t* __restrict__ c = win.blk + (ent & 0xffffu);
-            k0 = ld32(c);
-            k1 = ld32(c + 4);
-            k2 = ld32(c + 8);
-        }
-        kmask = __ballot(worth);                      // lanes outside [r, r+span) are dead or not yet covered
-        cov_end = (r + span < kWave) ? r + span : kWave;
-    }
-    // the table slot `h` now holds `entry`
-    __device__ __forceinline__ void wrote(const CursorWindow& win, uint32_t h, uint32_t entry)
-    {
-        const bool same = win.h0 == h;
-        ent = same ? entry : ent;
-        kmask &= ~__ballot(same);
-    }
-};
-
-// One probe (:344-348 / :393-398) at `ip`, which must be inside the window: returns the previous table entry, inserts
-// `ip`, and reports whether the 4 bytes at the candidate equal `cur`; on a hit `cb` holds the candidate's 12 bytes.
-template <class Table, uint32_t kAhead>
-__device__ __forceinline__ bool probe_cached(const Table& table, EntryCache<Table, kAhead>& ec, const CursorWindow& win,
-                                             const uint8_t* __restrict__ base16, uint64_t start, uint32_t ip, uint32_t cur,
-                                             uint32_t span, uint32_t lane, uint32_t& cand, CandidateBytes& cb)
-{
-    const uint32_t r = ip - win.base;
-    const uint32_t h = win.hash_at(ip);
-    const uint32_t mine = win.entry_at(ip);
-    if (r >= ec.cov_end) ec.gather(table, win, r, span, lane);
-    const uint32_t old = (uint32_t)__builtin_amdgcn_readlane((int)ec.ent, (int)r);
-    const bool cached_bytes = (ec.kmask >> r) & 1ull;     // before wrote() clears lane r's own bit
-    table.put(h, mine, lane);
-    ec.wrote(win, h, mine);
-    cand = old & 0xffffu;
-    if (Table::certain_miss(old, mine)) return false;
-    if (cached_bytes) {
-        cb.c0 = (uint32_t)__builtin_amdgcn_readlane((int)ec.k0, (int)r);
-        if (cb.c0 != cur) return false;
-        cb.c1 = (uint32_t)__builtin_amdgcn_readlane((int)ec.k1, (int)r);
-        cb.c2 = (uint32_t)__builtin_amdgcn_readlane((int)ec.k2, (int)r);
-        return true;
-    }
-    cb.fetch(base16, start + cand);                        // the slot was rewritten after the gather
-    return cb.c0 == cur;
-}
-
-// kAhead > 0 enables the speculative entry cache above; 0 is the plain serial probe.
-template <class Table, uint32_t kAhead = 0>
-__device__ __forceinline__ void compress_one_block_windowed(const uint8_t* __restrict__ base16, uint64_t start,
-                                                            uint64_t in_len, uint32_t n, uint8_t* __restrict__ dst,
-                                                            const Table table_in, uint32_t lane,
-                                                            uint32_t* __restrict__ block_bytes_out)
-{
-    const uint8_t* __restrict__ blk = base16 + start;
-    // get_hash_table, snappy_compress.c:139-146 (+ shift, :288)
-    const uint32_t ts = table_entries_for(n);
-    const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
-    // "empty" = candidate position 0 (:346 on a zeroed table), carrying position 0's tag
-    const uint32_t e_zero = (n >= kInputMargin) ? (((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u) : 0u;
-    const Table table = table_in.with_empty(e_zero);
-    if (n >= kInputMargin) table.init(ts, e_zero, lane);
-    __builtin_amdgcn_wave_barrier();
-
-    uint32_t op = 4;          // :291
-    uint32_t next_emit = 0;   // :298
-
-    if (n >= kInputMargin) {  // :301
-        const uint32_t limit = n - kInputMargin;
-        const uint64_t left = in_len - start;
-        CursorWindow win;
-        win.blk = blk;
-        win.avail = (left < 0x7fffffffull) ? (uint32_t)left : 0x7fffffffu;
-        win.shift = shift;
-        win.reset(0, lane);
-        EntryCache<Table, kAhead> ec;
-        uint32_t ip = 1;      // :305
-        for (;;) {
-            // ---- step 1: scan for a 4-byte match (:333-348) ----
-            uint32_t skip = 32;
-            uint32_t cand = 0;
-            CandidateBytes cb;
-            bool hit = false;
-            for (;;) {
-                if (win.ensure(ip, lane) && kAhead) ec.invalidate();
-                const uint32_t cur = win.bytes_at(ip);
-                const uint32_t stride = skip++ >> 5;
-                const uint32_t next_ip = ip + stride;
-                if (next_ip > limit) break;     // :342-343, before touching the table
-                if (kAhead) {
-                    // look ahead only while the scan moves one position at a time (:339); wider strides probe one slot
-                    hit = probe_cached<Table, kAhead>(table, ec, win, base16, start, ip, cur, stride == 1 ? kAhead : 1u, lane,
-                                                      cand, cb);
-                    if (hit) break;
-                } else {
-                    const uint32_t h = win.hash_at(ip);
-                    const uint32_t mine = win.entry_at(ip);
-                    const uint32_t old = table.exchange(h, mine, lane);
-                    cand = old & 0xffffu;
-                    if (!Table::certain_miss(old, mine)) {           // same tag: only now are the bytes worth fetching
-                        cb.fetch(base16, start + cand);
-                        if (cur == cb.c0) {
-                            hit = true;
-                            break;
-                        }
-                    }
-                }
-                ip = next_ip;
-            }
-            if (!hit) break;
-
-            // ---- step 2: literal run [next_emit, ip) (:355); ip is inside the window ----
-            op = emit_literal_windowed(dst, op, blk, next_emit, ip - next_emit, win.base, win.x0, lane);
-
-            // ---- step 3: copy chain (:370-398) ----
-            bool done = false;
-            for (;;) {
-                const uint32_t base = ip;
-                // find_match_length (:176-193): first 8 bytes on the scalar side, the rest by 64 lanes
-                const uint64_t mine = (uint64_t)win.bytes_near(ip + 4) | ((uint64_t)win.bytes_near(ip + 8) << 32);
-                const uint64_t diff = mine ^ cb.next8();
-                uint32_t matched;
-                if (diff) {
-                    matched = 4 + ((uint32_t)__builtin_ctzll(diff) >> 3);
-                } else {
-                    matched = 12 + match_extend(blk, cand + 12, ip + 12, n, lane);
-                }
-                ip += matched;
-                op = emit_copy_packed(dst, op, base - cand, matched, lane);
-                next_emit = ip;
-                if (ip >= limit) {              // :388-389
-                    done = true;
-                    break;
-                }
-                if (win.ensure(ip - 1, lane) && kAhead) ec.invalidate();
-                {
-                    const uint32_t hp = win.hash_at(ip - 1);
-                    const uint32_t ep = win.entry_at(ip - 1);
-                    table.put(hp, ep, lane);                                  // :391-392
-                    if (kAhead) ec.wrote(win, hp, ep);
-                }
-                if (win.ensure(ip, lane) && kAhead) ec.invalidate();
-                const uint32_t here = win.bytes_at(ip);
-                if (kAhead) {
-                    if (!probe_cached<Table, kAhead>(table, ec, win, base16, start, ip, here, kAhead, lane, cand, cb)) break;
-                } else {
-                    const uint32_t mine_e = win.entry_at(ip);
-                    const uint32_t old = table.exchange(win.hash_at(ip), mine_e, lane);   // :394-397
-                    cand = old & 0xffffu;
-                    if (Table::certain_miss(old, mine_e)) break;   // different tag: certain miss (:398)
-                    cb.fetch(base16, start + cand);
-                    if (here != cb.c0) break;                  // :396,:398
-                }
-            }
-            if (done) break;
-            ++ip;                                                // :400-401
-        }
-    }
-
-    // emit_remainder (:405-410) and the size prefix (:412)
-    if (next_emit < n) op = emit_literal(dst, op, blk + next_emit, n - next_emit, lane);
-    if (lane == 0) {
-        st32(dst, op - 4);
-        *block_bytes_out = op;
-    }
-    __builtin_amdgcn_wave_barrier();
-}
+#ifdef SNAPPY_ABLATION
+}  // namespace snappy_hip
+#include "ablation/k1_windowed_form.hpp"
+namespace snappy_hip {
+#endif
 
 // floor(x / d) for x < 64, 1 <= d < 64:  (x * kRecip16[d]) >> 16  with kRecip16[d] = 65536/d + 1
 __constant__ uint32_t kRecip16[64] = {
@@ -871,167 +567,11 @@ struct MaskedWindowState {
     }
 };
 
-// first 8 bytes of find_match_length (:176-193) on the scalar side, for a probe resolved by the serial exchange
-__device__ __forceinline__ uint32_t ext_from_candidate(const CursorWindow& win, uint32_t ip, const CandidateBytes& cb)
-{
-    const uint64_t mine = (uint64_t)win.bytes_near(ip + 4) | ((uint64_t)win.bytes_near(ip + 8) << 32);
-    const uint64_t diff = mine ^ cb.next8();
-    return diff ? ((uint32_t)__builtin_ctzll(diff) >> 3) : 8u;
-}
-
-template <class Table, uint32_t kChunk>
-__device__ __forceinline__ void compress_one_block_masked(const uint8_t* __restrict__ base16, uint64_t start, uint64_t in_len,
-                                                          uint32_t n, uint8_t* __restrict__ dst, const Table table_in,
-                                                          uint32_t lane, uint32_t* __restrict__ block_bytes_out,
-                                                          lds_bytes_t dup_scratch)
-{
-    using State = MaskedWindowState<Table, kChunk>;
-    const uint8_t* __restrict__ blk = base16 + start;
-    const uint32_t ts = table_entries_for(n);                    // get_hash_table, :139-146 (+ shift, :288)
-    const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
-    // "empty" = candidate position 0 (:346 on a zeroed table), carrying position 0's tag
-    const uint32_t e_zero = (n >= kInputMargin) ? (((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u) : 0u;
-    const Table table = table_in.with_empty(e_zero);
-    if (n >= kInputMargin) table.init(ts, e_zero, lane);
-    __builtin_amdgcn_wave_barrier();
-
-    uint32_t op = 4;          // :291
-    uint32_t next_emit = 0;   // :298
-
-    if (n >= kInputMargin) {  // :301
-        const uint32_t limit = n - kInputMargin;
-        const uint64_t left = in_len - start;
-        CursorWindow win;
-        win.blk = blk;
-        win.avail = (left < 0x7fffffffull) ? (uint32_t)left : 0x7fffffffu;
-        win.shift = shift;
-        win.reset(0, lane);
-        State st;
-        uint32_t ip = 1;      // :305
-        for (;;) {
-            // ---- step 1: scan for a 4-byte match (:333-348) ----
-            uint32_t skip = 32;
-            uint32_t cand = 0, ext = 0;
-            bool hit = false;
-            for (;;) {
-                const uint32_t stride = skip >> 5;
-                if (ip + stride > limit) break;                  // :342-343, before touching the table
-                if (win.ensure(ip, lane)) st.invalidate();
-                uint32_t r = ip - win.base;
-                if (r >= uni(st.cov_end)) st.gather(table, win, dup_scratch, r, stride == 1 ? kChunk : 1u, lane);
-                bool serial = true;
-                if (stride == 1) {
-                    // lanes [r, hi): resolved, probed one position apart, and allowed by :342 (position + 1 <= limit)
-                    uint32_t hi = uni(st.cov_end);
-                    const uint32_t budget = r + (64u - skip);    // the stride becomes 2 once skip reaches 64 (:339)
-                    hi = budget < hi ? budget : hi;
-                    const uint32_t lim = limit - win.base;
-                    hi = lim < hi ? lim : hi;
-                    const uint32_t run = hi - r;                 // >= 1
-                    const uint32_t f0 = ctz64_or((st.hit | st.dup) >> r, 64u);
-                    const uint32_t f = f0 < run ? f0 : run;      // plain misses in front of the first hit / DUP lane
-                    if (f) {
-                        State::commit(table, win, lane_range(r, f), lane);
-                        ip += f;
-                        skip += f;
-                    }
-                    if (f == run) continue;                      // coverage, stride-1 budget or limit ran out: re-evaluate
-                    r += f;
-                    serial = (st.dup >> r) & 1ull;
-                    if (!serial) {                               // a resolved hit
-                        State::commit(table, win, 1ull << r, lane);
-                        cand = (uint32_t)__builtin_amdgcn_readlane((int)st.ent, (int)r) & 0xffffu;
-                        ext = (uint32_t)__builtin_amdgcn_readlane((int)st.extv, (int)r);
-                        hit = true;
-                        break;
-                    }
-                } else {
-                    serial = (st.dup >> r) & 1ull;
-                    if (!serial) {
-                        State::commit(table, win, 1ull << r, lane);
-                        if ((st.hit >> r) & 1ull) {
-                            cand = (uint32_t)__builtin_amdgcn_readlane((int)st.ent, (int)r) & 0xffffu;
-                            ext = (uint32_t)__builtin_amdgcn_readlane((int)st.extv, (int)r);
-                            hit = true;
-                            break;
-                        }
-                        ip += stride;
-                        ++skip;
-                        continue;
-                    }
-                }
-                // serial probe: this lane shares its table slot with another lane of the window, ask the table itself
-                {
-                    const uint32_t cur = win.bytes_at(ip);
-                    const uint32_t mine = win.entry_at(ip);
-                    const uint32_t old = table.exchange(win.hash_at(ip), mine, lane);
-                    cand = old & 0xffffu;
-                    if (!Table::certain_miss(old, mine)) {
-                        CandidateBytes cb;
-                        cb.fetch(base16, start + cand);
-                        if (cur == cb.c0) {
-                            ext = ext_from_candidate(win, ip, cb);
-                            hit = true;
-                            break;
-                        }
-                    }
-                    ip += skip >> 5;
-                    ++skip;
-                }
-            }
-            if (!hit) break;
-
-            // ---- step 2: literal run [next_emit, ip) (:355); ip is inside the window ----
-            op = emit_literal_windowed(dst, op, blk, next_emit, ip - next_emit, win.base, win.x0, lane);
-
-            // ---- step 3: copy chain (:370-398) ----
-            bool done = false;
-            for (;;) {
-                const uint32_t mbase = ip;
-                uint32_t matched = 4 + ext;                      // find_match_length (:176-193)
-                if (ext == 8) matched = 12 + match_extend(blk, cand + 12, ip + 12, n, lane);
-                ip += matched;
-                op = emit_copy_packed(dst, op, mbase - cand, matched, lane);
-                next_emit = ip;
-                if (ip >= limit) {                               // :388-389
-                    done = true;
-                    break;
-                }
-                if (win.ensure(ip - 1, lane)) st.invalidate();
-                State::commit(table, win, 1ull << (ip - 1 - win.base), lane);   // :391-392
-                if (win.ensure(ip, lane)) st.invalidate();
-                const uint32_t r = ip - win.base;
-                if (r >= uni(st.cov_end)) st.gather(table, win, dup_scratch, r, kChunk, lane);
-                if (!((st.dup >> r) & 1ull)) {                   // :393-398 from the cache
-                    State::commit(table, win, 1ull << r, lane);
-                    if (!((st.hit >> r) & 1ull)) break;
-                    cand = (uint32_t)__builtin_amdgcn_readlane((int)st.ent, (int)r) & 0xffffu;
-                    ext = (uint32_t)__builtin_amdgcn_readlane((int)st.extv, (int)r);
-                } else {
-                    const uint32_t here = win.bytes_at(ip);
-                    const uint32_t mine_e = win.entry_at(ip);
-                    const uint32_t old = table.exchange(win.hash_at(ip), mine_e, lane);
-                    cand = old & 0xffffu;
-                    if (Table::certain_miss(old, mine_e)) break;
-                    CandidateBytes cb;
-                    cb.fetch(base16, start + cand);
-                    if (here != cb.c0) break;
-                    ext = ext_from_candidate(win, ip, cb);
-                }
-            }
-            if (done) break;
-            ++ip;                                                // :400-401
-        }
-    }
-
-    // emit_remainder (:405-410) and the size prefix (:412)
-    if (next_emit < n) op = emit_literal(dst, op, blk + next_emit, n - next_emit, lane);
-    if (lane == 0) {
-        st32(dst, op - 4);
-        *block_bytes_out = op;
-    }
-    __builtin_amdgcn_wave_barrier();
-}
+#ifdef SNAPPY_ABLATION
+}  // namespace snappy_hip
+#include "ablation/k1_masked_form.hpp"
+namespace snappy_hip {
+#endif
 
 // ---------------------------------------------------------------------------
 // K1, bulk form: the masked form with the per-match work moved off the scalar chain.  Within one window, for as long as
@@ -1471,14 +1011,18 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const K1B
         const uint64_t start = (uint64_t)lb * block_size;
         const uint64_t left = in_len - start;
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
-        if (kForm == 2)
-            compress_one_block_bulk<LdsTable, kAhead>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out,
-                                                      (lds_bytes_t)dup_scratch);
-        else if (kForm == 1)
+#ifdef SNAPPY_ABLATION
+        if constexpr (kForm == 1)
             compress_one_block_masked<LdsTable, kAhead>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out,
                                                         (lds_bytes_t)dup_scratch);
-        else
+        else if constexpr (kForm == 0)
             compress_one_block_windowed<LdsTable, kAhead>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out);
+        else
+#else
+        static_assert(kForm == 2, "the product ships the bulk form; other forms need -DSNAPPY_ABLATION");
+#endif
+            compress_one_block_bulk<LdsTable, kAhead>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out,
+                                                      (lds_bytes_t)dup_scratch);
         if (next_block && lane == 0) atomicAdd(next_block + 4, 1u);   // statistics: blocks taken by the LDS-table form
         __syncthreads();
         b += gridDim.x;
@@ -1493,18 +1037,25 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
     __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kForm ? kDupSlots : 16];
     __shared__ __attribute__((aligned(16))) uint32_t slot_state[kFilter == 2 ? kMaxTableEntries / 16 : (kFilter ? kMaxTableEntries / 32 : 4)];
     const uint32_t lane = threadIdx.x;
+#ifdef SNAPPY_ABLATION
     using Table = typename std::conditional<kFilter == 2, ClassFilteredGlobalTable,
                                             typename std::conditional<kFilter == 1, FilteredGlobalTable, TaggedGlobalTable>::type>::type;
+#else
+    static_assert(kForm == 2 && kFilter == 1, "the product ships the bulk form behind the slot filter; other forms need -DSNAPPY_ABLATION");
+    using Table = FilteredGlobalTable;
+#endif
     Table table;
     table.t = table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
     if constexpr (kFilter == 1) {
         table.written = (lds_words_t)slot_state;
         table.empty = 0;
     }
+#ifdef SNAPPY_ABLATION
     if constexpr (kFilter == 2) {
         table.cls = (lds_words_t)slot_state;
         table.empty = 0;
     }
+#endif
     for (;;) {
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(next_block, 1u);
@@ -1519,12 +1070,14 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
         const uint64_t start = (uint64_t)lb * block_size;
         const uint64_t left = in_len - start;
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
-        if (kForm == 2)
-            compress_one_block_bulk<Table, kAhead>(in, start, in_len, n, slot, table, lane, bytes_out, (lds_bytes_t)dup_scratch);
-        else if (kForm == 1)
+#ifdef SNAPPY_ABLATION
+        if constexpr (kForm == 1)
             compress_one_block_masked<Table, kAhead>(in, start, in_len, n, slot, table, lane, bytes_out, (lds_bytes_t)dup_scratch);
-        else
+        else if constexpr (kForm == 0)
             compress_one_block_windowed<Table, kAhead>(in, start, in_len, n, slot, table, lane, bytes_out);
+        else
+#endif
+            compress_one_block_bulk<Table, kAhead>(in, start, in_len, n, slot, table, lane, bytes_out, (lds_bytes_t)dup_scratch);
     }
 }
 
@@ -1532,392 +1085,11 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
 #include "snappy_k1_pair.hpp"
 namespace snappy_hip {
 
-// ---------------------------------------------------------------------------
-// K1, lane-per-block form: every LANE owns one Snappy block (64 blocks per wavefront) and runs the
-// sequential parse as ordinary SIMT code -- all VALU, no wave-uniform scalar chain, so one
-// wave-instruction advances up to 64 parses.  Each lane's u16 hash table (<= 32 KiB) lives in a global
-// scratch; the dependent table -> candidate loads are hidden by the other resident waves.
-// Same bytes as compress_one_block (snappy_compress.c:284-413).
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lane_emit_literal(uint8_t* __restrict__ dst, uint32_t op,
-                                                      const uint8_t* __restrict__ src, uint32_t len)
-{
-    const uint32_t n = len - 1;                                  // snappy_compress.c:202-225
-    if (n < 60) {
-        dst[op++] = (uint8_t)(n << 2);
-    } else if (n < 256) {
-        dst[op++] = (uint8_t)(60 << 2);
-        dst[op++] = (uint8_t)n;
-    } else if (n < 65536) {
-        dst[op++] = (uint8_t)(61 << 2);
-        dst[op++] = (uint8_t)n;
-        dst[op++] = (uint8_t)(n >> 8);
-    } else {
-        dst[op++] = (uint8_t)(62 << 2);
-        dst[op++] = (uint8_t)n;
-        dst[op++] = (uint8_t)(n >> 8);
-        dst[op++] = (uint8_t)(n >> 16);
-    }
-    uint32_t i = 0;
-    for (; i + 4 <= len; i += 4) st32(dst + op + i, ld32(src + i));
-    for (; i < len; ++i) dst[op + i] = src[i];
-    return op + len;
-}
-
-__device__ __forceinline__ uint32_t lane_emit_copy(uint8_t* __restrict__ dst, uint32_t op, uint32_t off, uint32_t len)
-{
-    for (;;) {                                                   // snappy_compress.c:234-272
-        uint32_t piece = len;
-        if (len >= 68) piece = 64;
-        else if (len > 64) piece = 60;
-        if (piece < 12 && off < 2048) {
-            dst[op++] = (uint8_t)(1 + ((piece - 4) << 2) + ((off >> 8) << 5));
-            dst[op++] = (uint8_t)off;
-        } else {
-            dst[op++] = (uint8_t)(2 + ((piece - 1) << 2));
-            dst[op++] = (uint8_t)off;
-            dst[op++] = (uint8_t)(off >> 8);
-        }
-        len -= piece;
-        if (len == 0) return op;
-    }
-}
-
-__global__ __launch_bounds__(64) void compress_blocks_lane_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
-                                                                  uint32_t block_size, uint8_t* __restrict__ slots,
-                                                                  uint32_t slot_stride, uint32_t* __restrict__ block_bytes,
-                                                                  uint32_t num_blocks, uint16_t* __restrict__ tables,
-                                                                  uint32_t lanes_per_block)
-{
-    // lanes_per_block > 1 replicates each block's (identical) work over a lane group: fewer blocks per wave,
-    // same addresses within a group (coalesced), more waves for the same number of blocks.
-    const uint32_t b = (blockIdx.x * 64 + threadIdx.x) / lanes_per_block;
-    if (b >= num_blocks) return;
-    const uint64_t start = (uint64_t)b * block_size;
-    const uint64_t left = in_len - start;
-    const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
-    const uint8_t* __restrict__ blk = in + start;
-    uint8_t* __restrict__ dst = slots + (uint64_t)b * slot_stride;
-    uint16_t* __restrict__ table = tables + (size_t)b * kMaxTableEntries;
-
-    const uint32_t ts = table_entries_for(n);                    // snappy_compress.c:139-146
-    const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;      // :288
-    {
-        uint4* t = reinterpret_cast<uint4*>(table);
-        for (uint32_t i = 0; i < ts / 8; ++i) t[i] = make_uint4(0, 0, 0, 0);
-    }
-    uint32_t op = 4, next_emit = 0;
-    if (n >= kInputMargin) {
-        const uint32_t limit = n - kInputMargin;
-        uint32_t ip = 1;
-        uint32_t cur = ld32(blk + ip);
-        for (;;) {
-            uint32_t skip = 32, cand;
-            bool out_of_input = false;
-            for (;;) {                                           // :336-348
-                const uint32_t h = (cur * kHashMul) >> shift;
-                const uint32_t next_ip = ip + (skip++ >> 5);
-                if (next_ip > limit) {
-                    out_of_input = true;
-                    break;
-                }
-                const uint32_t nxt = ld32(blk + next_ip);
-                cand = table[h];
-                table[h] = (uint16_t)ip;
-                if (cur == ld32(blk + cand)) break;
-                ip = next_ip;
-                cur = nxt;
-            }
-            if (out_of_input) break;
-            op = lane_emit_literal(dst, op, blk + next_emit, ip - next_emit);   // :355
-            bool done = false;
-            uint32_t tail = 0;
-            for (;;) {                                           // :370-398
-                const uint32_t base = ip;
-                uint32_t a = cand + 4;
-                ip += 4;
-                while (ip + 4 <= n && ld32(blk + ip) == ld32(blk + a)) {        // :176-193
-                    ip += 4;
-                    a += 4;
-                }
-                while (ip < n && blk[ip] == blk[a]) {
-                    ++ip;
-                    ++a;
-                }
-                op = lane_emit_copy(dst, op, base - cand, ip - base);
-                next_emit = ip;
-                if (ip >= limit) {
-                    done = true;
-                    break;
-                }
-                const uint64_t w = ld64(blk + ip - 1);
-                const uint32_t here = (uint32_t)(w >> 8);
-                tail = (uint32_t)(w >> 16);
-                table[((uint32_t)w * kHashMul) >> shift] = (uint16_t)(ip - 1);
-                const uint32_t hc = (here * kHashMul) >> shift;
-                cand = table[hc];
-                table[hc] = (uint16_t)ip;
-                if (here != ld32(blk + cand)) break;
-            }
-            if (done) break;
-            ++ip;
-            cur = tail;
-        }
-    }
-    if (next_emit < n) op = lane_emit_literal(dst, op, blk + next_emit, n - next_emit);   // :405-410
-    st32(dst, op - 4);                                           // :412
-    block_bytes[b] = op;
-}
-
-// ---------------------------------------------------------------------------
-// K1, group form (ablation, SNAPPY_HIP_COMPRESS_VARIANT=5): FOUR blocks per wavefront.  Each 16-lane group owns
-// one block; the parse is a flat state machine executed as predicated VALU code -- every loop iteration performs
-// ONE probe (scan probe or post-copy probe, snappy_compress.c:336-348 / :391-398) for each of the wave's four
-// groups, so one wave-instruction advances four parses and four independent table -> candidate chains are in
-// flight per wave, none of it on the scalar unit.  Group-uniform state is replicated in the group's lanes; the
-// lanes cooperate on table clears, literal payloads and multi-piece copies.  Hash tables: one u16[16384] per
-// group in a global scratch.  Groups pull blocks from a shared atomic counter.
-// The only wave collective is the loop condition; wave_barrier()s at the top level of the loop body separate
-// the table store -> load -> store phases (free on hardware, where a wave runs in lockstep).
-// Measured: 26.8 GB/s with 32768 groups in flight (5.4 us per iteration: three dependent HBM-random accesses),
-// i.e. not faster than the wave-per-block form; kept as the starting point for the tag-filtered table idea.
-// ---------------------------------------------------------------------------
-constexpr uint32_t kGroupLanes = 16;
-
-__device__ __forceinline__ uint32_t group_emit_literal(uint8_t* dst, uint32_t op, const uint8_t* src, uint32_t len,
-                                                       uint32_t gl)
-{
-    const uint32_t n1 = len - 1;                                 // snappy_compress.c:202-225
-    const uint32_t hdr = (n1 < 60) ? 1u : ((n1 < 256u) ? 2u : ((n1 < 65536u) ? 3u : 4u));
-    if (gl < hdr) {
-        const uint32_t tag = (n1 < 60) ? (n1 << 2) : ((58 + hdr) << 2);
-        dst[op + gl] = (gl == 0) ? (uint8_t)tag : (uint8_t)(n1 >> (8 * (gl - 1)));
-    }
-    for (uint32_t i = gl; i < len; i += kGroupLanes) dst[op + hdr + i] = src[i];
-    return op + hdr + len;
-}
-
-__device__ __forceinline__ uint32_t group_emit_copy(uint8_t* dst, uint32_t op, uint32_t off, uint32_t len, uint32_t gl)
-{
-    if (len > 64) {                                              // snappy_compress.c:254-272
-        const uint32_t n64 = (len >= 68) ? ((len - 68) / 64 + 1) : 0;
-        len -= 64 * n64;
-        const uint32_t has60 = (len > 64) ? 1u : 0u;
-        if (has60) len -= 60;
-        const uint32_t nfull = n64 + has60;
-        for (uint32_t k = gl; k < nfull; k += kGroupLanes) {
-            const uint32_t plen = (k < n64) ? 64u : 60u;
-            uint8_t* p = dst + op + 3 * k;
-            p[0] = (uint8_t)(2 + ((plen - 1) << 2));
-            p[1] = (uint8_t)off;
-            p[2] = (uint8_t)(off >> 8);
-        }
-        op += 3 * nfull;
-    }
-    if (len < 12 && off < 2048) {                                // snappy_compress.c:234-245
-        if (gl < 2) dst[op + gl] = (gl == 0) ? (uint8_t)(1 + ((len - 4) << 2) + ((off >> 8) << 5)) : (uint8_t)off;
-        return op + 2;
-    }
-    if (gl < 3) dst[op + gl] = (gl == 0) ? (uint8_t)(2 + ((len - 1) << 2)) : ((gl == 1) ? (uint8_t)off : (uint8_t)(off >> 8));
-    return op + 3;
-}
-
-// broadcast a value from the group's leader lane to the whole 16-lane group (LDS crossbar, no memory)
-__device__ __forceinline__ uint32_t group_bcast(uint32_t v, uint32_t leader) { return (uint32_t)__shfl((int)v, (int)leader); }
-__device__ __forceinline__ uint64_t group_bcast64(uint64_t v, uint32_t leader)
-{
-    return (uint64_t)group_bcast((uint32_t)v, leader) | ((uint64_t)group_bcast((uint32_t)(v >> 32), leader) << 32);
-}
-
-__global__ __launch_bounds__(64) void compress_blocks_group_kernel(const uint8_t* __restrict__ in, uint64_t in_len,
-                                                                   uint32_t block_size, uint8_t* __restrict__ slots,
-                                                                   uint32_t slot_stride, uint32_t* __restrict__ block_bytes,
-                                                                   uint32_t num_blocks, uint32_t* tables,
-                                                                   uint32_t* next_block)
-{
-    enum : uint32_t { kInit = 0, kScan = 1, kCopy = 2, kDone = 3 };
-    const uint32_t lane = threadIdx.x;
-    const uint32_t gl = lane & (kGroupLanes - 1);
-    const uint32_t leader = lane & ~(kGroupLanes - 1);
-    const bool lead = gl == 0;
-    const uint32_t groups_per_wave = kWave / kGroupLanes;
-    const uint32_t slot = blockIdx.x * groups_per_wave + (lane / kGroupLanes);
-    const uint32_t total_slots = gridDim.x * groups_per_wave;
-    uint32_t* table = tables + (size_t)slot * kMaxTableEntries;   // tagged entries: tag << 16 | position
-
-    uint32_t mode = kInit;
-    uint32_t n = 0, limit = 0, shift = 0, ip = 0, skip = 32, next_emit = 0, op = 4, cur_block = 0;
-    const uint8_t* blk = in;
-    uint8_t* dst = slots;
-    // cursor cache: the 16 bytes at block offset cbase, so most probes need no cursor load
-    uint32_t cbase = 0;
-    uint64_t clo = 0, chi = 0;
-    (void)total_slots;
-
-    // Memory discipline: every (group-uniform) global load is issued by the group's leader lane only and
-    // broadcast with group_bcast -- 4 active lanes per wave-instruction instead of 64 redundant ones.
-    while (__ballot(mode != kDone)) {
-        // ---------------- block start (get_hash_table, snappy_compress.c:139-146, :288-301) ----------------
-        // Groups pull blocks from a shared counter (*next_block zeroed per launch), so a group that drew a
-        // cheap block simply takes another one.
-        bool fresh = false;
-        const bool want = (mode == kInit);
-        if (__ballot(want)) {
-            uint32_t drawn = 0;
-            if (want && lead) drawn = atomicAdd(next_block, 1u);
-            drawn = group_bcast(drawn, leader);
-            if (want) {
-                if (drawn >= num_blocks) {
-                    mode = kDone;
-                } else {
-                    cur_block = drawn;
-                    const uint64_t start = (uint64_t)cur_block * block_size;
-                    const uint64_t left = in_len - start;
-                    n = (left < block_size) ? (uint32_t)left : block_size;
-                    blk = in + start;
-                    dst = slots + (uint64_t)cur_block * slot_stride;
-                    op = 4;
-                    next_emit = 0;
-                    if (n < kInputMargin) {                      // whole block is one literal (:405-412)
-                        op = group_emit_literal(dst, op, blk, n, gl);
-                        if (lead) {
-                            st32(dst, op - 4);
-                            block_bytes[cur_block] = op;
-                        }
-                    } else {
-                        const uint32_t ts = table_entries_for(n);
-                        shift = (uint32_t)__builtin_clz(ts) + 1;
-                        limit = n - kInputMargin;
-                        ip = 1;
-                        skip = 32;
-                        cbase = 0;
-                        mode = kScan;
-                        fresh = true;
-                    }
-                }
-            }
-        }
-        const bool probing = (mode == kScan) || (mode == kCopy);
-
-        // ---------------- phase A0: (re)load the cursor cache when bytes ip-1 .. ip+6 are not inside it ----------------
-        const bool reload = probing && (fresh || ip - 1 < cbase || ip + 7 > cbase + 16);
-        if (__ballot(reload)) {
-            if (reload) {
-                if (!fresh) cbase = (ip - 1 + 16 <= n) ? ip - 1 : n - 16;
-                if (lead) {
-                    clo = ld64(blk + cbase);
-                    chi = (cbase + 16 <= n) ? ld64(blk + cbase + 8) : 0;   // only a 15-byte block lacks the 16th byte
-                }
-            }
-            clo = group_bcast64(clo, leader);
-            chi = group_bcast64(chi, leader);
-        }
-        if (fresh) {
-            // an empty slot means "candidate = position 0" (:346 on a zeroed table): store position 0's entry
-            const uint32_t e_zero = (((uint32_t)clo * kHashMul) << (32 - shift)) & 0xffff0000u;
-            const uint32_t ts = table_entries_for(n);
-            uint4* t = reinterpret_cast<uint4*>(table);
-            for (uint32_t i = gl; i < ts / 4; i += kGroupLanes) t[i] = make_uint4(e_zero, e_zero, e_zero, e_zero);
-        }
-
-        // ---------------- phase A: cursor bytes; post-copy insert of ip-1 (:391-392) ----------------
-        uint32_t cur = 0, h = 0, mine = 0, next_ip = 0;
-        bool exhausted = false;
-        if (probing) {
-            const uint32_t sh = 8 * (ip - 1 - cbase);            // 0..64 bits
-            const uint64_t w = (sh == 0) ? clo : ((sh < 64) ? ((clo >> sh) | (chi << (64 - sh))) : chi);
-            cur = (uint32_t)(w >> 8);
-            const uint32_t prod = cur * kHashMul;
-            h = prod >> shift;
-            mine = ((prod << (32 - shift)) & 0xffff0000u) | ip;
-            if (mode == kCopy) {
-                const uint32_t pprod = (uint32_t)w * kHashMul;
-                if (lead) table[pprod >> shift] = ((pprod << (32 - shift)) & 0xffff0000u) | (ip - 1);
-            } else {
-                next_ip = ip + (skip >> 5);                      // :339-343
-                ++skip;
-                exhausted = next_ip > limit;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---------------- phase B: candidate lookup (:346, :395) ----------------
-        const bool lookup = probing && !exhausted;
-        uint32_t old = 0;
-        if (lookup && lead) old = table[h];
-        old = group_bcast(old, leader);
-        // ---------------- phase C: table update, hit test ----------------
-        if (lookup && lead) table[h] = mine;                     // :347, :397
-        const uint32_t cand = old & 0xffffu;
-        const bool tagmatch = lookup && (((old ^ mine) >> 16) == 0);
-        bool hit = false;
-        uint64_t c01 = 0;
-        uint32_t c2 = 0;
-        if (__ballot(tagmatch)) {                                // same tag: fetch candidate bytes (cand + 16 <= n)
-            if (tagmatch && lead) {
-                c01 = ld64(blk + cand);
-                c2 = ld32(blk + cand + 8);
-            }
-            c01 = group_bcast64(c01, leader);
-            c2 = group_bcast(c2, leader);
-            hit = tagmatch && (cur == (uint32_t)c01);
-        }
-        if (lookup && !hit) {
-            // miss: keep scanning (:348) or fall back from the copy chain to scanning (:398-401)
-            if (mode == kCopy) {
-                mode = kScan;
-                skip = 32;
-                ip += 1;
-            } else {
-                ip = next_ip;
-            }
-        }
-        // ---------------- phase D: hit path -- literal, match length, copy (:355-389) ----------------
-        if (__ballot(hit)) {
-            uint64_t ahead = 0;
-            if (hit && lead) ahead = ld64(blk + ip + 4);
-            ahead = group_bcast64(ahead, leader);
-            if (hit) {
-                if (mode == kScan) op = group_emit_literal(dst, op, blk + next_emit, ip - next_emit, gl);   // :355
-                // find_match_length (:176-193): 8 bytes at once, then 8-byte / 1-byte steps
-                const uint64_t theirs = (c01 >> 32) | ((uint64_t)c2 << 32);
-                const uint64_t diff = ahead ^ theirs;
-                uint32_t matched;
-                if (diff) {
-                    matched = 4 + ((uint32_t)__builtin_ctzll(diff) >> 3);
-                } else {
-                    matched = 12;
-                    while (ip + matched + 8 <= n) {
-                        const uint64_t d = ld64(blk + ip + matched) ^ ld64(blk + cand + matched);
-                        if (d) {
-                            matched += (uint32_t)__builtin_ctzll(d) >> 3;
-                            break;
-                        }
-                        matched += 8;
-                    }
-                    if (ip + matched + 8 > n)
-                        while (ip + matched < n && blk[ip + matched] == blk[cand + matched]) ++matched;
-                }
-                op = group_emit_copy(dst, op, ip - cand, matched, gl);   // :380
-                ip += matched;
-                next_emit = ip;
-                if (ip >= limit) exhausted = true;               // :388-389
-                else mode = kCopy;
-            }
-        }
-        if (probing && exhausted) {                              // emit_remainder (:405-412)
-            if (next_emit < n) op = group_emit_literal(dst, op, blk + next_emit, n - next_emit, gl);
-            if (lead) {
-                st32(dst, op - 4);
-                block_bytes[cur_block] = op;
-            }
-            mode = kInit;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// scan + gather: slots -> contiguous framed stream
-// ---------------------------------------------------------------------------
+#ifdef SNAPPY_ABLATION
+}  // namespace snappy_hip
+#include "ablation/k1_simt_kernels.hpp"
+namespace snappy_hip {
+#endif
 
 // Single-workgroup exclusive scan (<= 131072 blocks per 4 GiB container at 32 KiB; any count
 // works, it loops).  Also writes the two header varints (snappy_compress.c:461-465).

@@ -67,3 +67,25 @@ def test_no_cpu_fallback_without_gpu():
     assert st != 0 and stream == b""
     st, plain, _ = shb.decompress_host(golden_bytes("alice.snappy"))
     assert st != 0 and plain == b""
+
+
+def test_k2_back_references_use_global_not_flat_instructions(tmp_path):
+    """K2 serves a back-reference with a load issued after the store of the same wavefront and no s_waitcnt in between
+    (csrc/snappy_kernels.hpp, decompress_blocks_kernel).  That relies on vector memory operations of one wavefront
+    completing in issue order, which holds for global_* instructions but NOT for flat_* ones
+    (MI355X_MICROARCH.md: "flat_* excepted: out of order").  So the invariant is checked on the generated code: the shipped
+    decoder must not contain a single flat_load / flat_store / flat_atomic."""
+    import subprocess
+    src = os.path.join(ROOT, "pim-compression_amd", "csrc", "snappy_hip.hip")
+    asm = tmp_path / "device.s"
+    subprocess.check_call([entry.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", str(asm)])
+    text = asm.read_text()
+    m = re.search(r"^(_ZN10snappy_hip24decompress_blocks_kernelILb0EE\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
+    assert m, "decompress_blocks_kernel<false> not found in the device code"
+    body = m.group(2)
+    assert len(re.findall(r"^\s*global_(?:load|store)", body, re.M)) >= 20
+    assert re.findall(r"^\s*flat_\w+", body, re.M) == []
+    # and the product library carries exactly one K1 pair, the two-wavefront form, and one K2 (no ablation instantiations)
+    kernels = set(re.findall(r"^\s*\.amdhsa_kernel (\S+)", text, re.M))
+    k1 = sorted(k for k in kernels if "_blocks_" in k and "decompress" not in k)
+    assert len(k1) == 3 and len([k for k in kernels if "decompress_blocks_kernel" in k]) == 1, sorted(kernels)

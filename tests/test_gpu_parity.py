@@ -345,39 +345,18 @@ def test_seeded_fuzz_vs_oracle(shb):
 
 # ---- every kernel variant produces the same bytes ------------------------------------------------------
 
-# K1 default = bulk form + slot filter (global-table kernel) beside the bulk LDS-table kernel; F0 = the windowed form
-F0 = {"SNAPPY_HIP_K1_FORM": "0", "SNAPPY_HIP_K1_FILTER": "0", "SNAPPY_HIP_K1_FORM_LDS": "0"}
+# The shipped K1 / K2 set: the concurrent launch (global-table + LDS-table kernels, bulk parse), each kernel alone, tiny grids,
+# and the two-wavefront LDS form alone / beside global-table wavefronts.  The non-default forms of round 1 live in
+# csrc/ablation/ and are checked by tests/test_gpu_ablation.py against their own build.
 TINY_HYBRID = {"SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11", "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"}
 
 
 @pytest.mark.parametrize("env", [{"SNAPPY_HIP_PAIR_PER_CU": "4", "SNAPPY_HIP_GT_WAVES": "0"}, {"SNAPPY_HIP_PAIR_PER_CU": "3"},
                                  {"SNAPPY_HIP_PAIR_PER_CU": "1", "SNAPPY_HIP_GT_WAVES": "64"},
-                                 {"SNAPPY_HIP_COMPRESS_VARIANT": "1"}, {"SNAPPY_HIP_COMPRESS_VARIANT": "4"},
-                                 {"SNAPPY_HIP_COMPRESS_VARIANT": "4", "SNAPPY_HIP_LANES_PER_BLOCK": "16"},
+                                 {"SNAPPY_HIP_COMPRESS_VARIANT": "1"},
                                  {"SNAPPY_HIP_COMPRESS_VARIANT": "3", "SNAPPY_HIP_GT_WAVES": "7"},
-                                 {"SNAPPY_HIP_COMPRESS_VARIANT": "5"},
-                                 {"SNAPPY_HIP_COMPRESS_VARIANT": "5", "SNAPPY_HIP_GROUP_WAVES": "3"},
-                                 {"SNAPPY_HIP_LDS_WAVES": "0"}, TINY_HYBRID,
-                                 # windowed form: serial probes and look-ahead widths
-                                 {**F0, "SNAPPY_HIP_K1_AHEAD": "0", "SNAPPY_HIP_K1_AHEAD_LDS": "0"},
-                                 {**F0, "SNAPPY_HIP_K1_AHEAD": "8"}, {**F0, "SNAPPY_HIP_K1_AHEAD": "16"}, {**F0},
-                                 {**F0, "SNAPPY_HIP_LDS_WAVES": "1024"},
-                                 {**F0, "SNAPPY_HIP_K1_AHEAD_LDS": "8", "SNAPPY_HIP_COMPRESS_VARIANT": "1"},
-                                 {**F0, **TINY_HYBRID, "SNAPPY_HIP_K1_AHEAD": "16"},
-                                 {**F0, "SNAPPY_HIP_K1_FILTER": "1"},
-                                 # masked form
-                                 {"SNAPPY_HIP_K1_FORM": "1", "SNAPPY_HIP_K1_FILTER": "0", "SNAPPY_HIP_K1_AHEAD": "32"},
-                                 {"SNAPPY_HIP_K1_FORM": "1", "SNAPPY_HIP_K1_FORM_LDS": "1", **TINY_HYBRID},
-                                 {"SNAPPY_HIP_K1_FORM": "1"},
-                                 {"SNAPPY_HIP_K1_FORM_LDS": "1", "SNAPPY_HIP_K1_AHEAD_LDS": "32", "SNAPPY_HIP_COMPRESS_VARIANT": "1"},
-                                 # bulk form: without filter, narrower chunks, alone
-                                 {"SNAPPY_HIP_K1_FILTER": "0"}, {"SNAPPY_HIP_K1_FILTER": "0", "SNAPPY_HIP_K1_AHEAD": "32"},
-                                 {"SNAPPY_HIP_K1_AHEAD": "32", **TINY_HYBRID},
-                                 {"SNAPPY_HIP_K1_AHEAD_LDS": "32", "SNAPPY_HIP_COMPRESS_VARIANT": "1"},
-                                 {"SNAPPY_HIP_K1_FILTER": "2", "SNAPPY_HIP_LDS_WAVES": "0"}, {"SNAPPY_HIP_K1_FILTER": "2", **TINY_HYBRID},
-                                 {"SNAPPY_HIP_DECOMPRESS_VARIANT": "0"},
-                                 {"SNAPPY_HIP_DECOMPRESS_VARIANT": "2", "SNAPPY_HIP_K2_LDS_WAVES": "3",
-                                  "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"}])
+                                 {"SNAPPY_HIP_LDS_WAVES": "0"}, {"SNAPPY_HIP_LDS_WAVES": "1024"}, TINY_HYBRID,
+                                 {"SNAPPY_HIP_K2_WAVES": "5"}])
 def test_kernel_variants_bit_exact(shb, env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
