@@ -215,6 +215,24 @@ int snappy_hip_decompress_blocks(const uint8_t *d_stream, uint64_t stream_len, c
                                  uint64_t total_len, uint32_t block_size,
                                  uint8_t *d_out, uint32_t *d_status, void *stream);
 
+/*
+ * K2 over a batch of streams in ONE launch: the same per-block semantics as snappy_hip_decompress_blocks for every item
+ * (its own stream, block offsets, output and status arrays; all with the same block_size), the persistent wavefronts
+ * drawing blocks of all streams from one counter, so the batch has one tail instead of one per stream -- the device-side
+ * form of the reference decoding many independent files, one `dpu_snappy` run each (snappy/dpu_snappy.c:186-192).  items is
+ * a HOST array, empty streams are skipped, lists longer than 8 non-empty streams are issued as several launches.
+ */
+struct snappy_hip_decompress_item {
+    const void *d_stream;          /* device: the framed stream (its header)                */
+    uint64_t stream_len;
+    const void *d_block_offsets;   /* device: num_blocks(total_len) u64                     */
+    uint64_t total_len;            /* uncompressed length from the header                   */
+    void *d_out;                   /* device: total_len bytes                               */
+    void *d_status;                /* device: num_blocks(total_len) u32                     */
+};
+int snappy_hip_decompress_blocks_batch(const struct snappy_hip_decompress_item *items, uint32_t count, uint32_t block_size,
+                                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

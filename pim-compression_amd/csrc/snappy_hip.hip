@@ -764,17 +764,14 @@ int snappy_hip_verify_index(const snappy_hip_stream_desc* d_descs, uint32_t coun
     return SNAPPY_HIP_OK;
 }
 
-int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, const uint64_t* d_block_offsets,
-                                 uint64_t total_len, uint32_t block_size, uint8_t* d_out, uint32_t* d_status, void* stream)
+// K2 over a batch of streams (count >= 1, every stream non-empty and validated by the callers below)
+static int launch_decompress(const snappy_hip::K2Batch& w, uint32_t block_size, void* stream)
 {
-    if (total_len == 0) return SNAPPY_HIP_OK;
-    if (!block_size_ok(block_size)) return fail(SNAPPY_HIP_ERR_ARG, "block_size must be 1..65535");
-    if (!d_stream || !d_block_offsets || !d_out || !d_status) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
-    const uint64_t nb = snappy_hip_num_blocks(total_len, block_size);
-    if (nb > 0x7fffffffull) return fail(SNAPPY_HIP_ERR_ARG, "too many blocks");
+    const uint64_t nb = w.first_block[w.count];
     hipStream_t st = (hipStream_t)stream;
     // every block's status starts as "not decoded": a block the launch never reaches cannot read back as OK
-    HIP_TRY(hipMemsetAsync(d_status, 0xff, nb * sizeof(uint32_t), st));
+    for (uint32_t c = 0; c < w.count; ++c)
+        HIP_TRY(hipMemsetAsync(w.status[c], 0xff, (size_t)(w.first_block[c + 1] - w.first_block[c]) * sizeof(uint32_t), st));
     WorkCounter wc;
     if (int rc = next_work_counter(&wc, st)) return rc;
     uint32_t* counter = wc.ptr;
@@ -798,15 +795,12 @@ int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, c
         hipEvent_t ev_begin = cr->ev_begin, ev_end = cr->ev_end;
         HIP_TRY(hipEventRecord(ev_begin, st));
         HIP_TRY(hipStreamWaitEvent(helper, ev_begin, 0));
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, helper, d_stream,
-                           stream_len, d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb, counter);
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, helper, w, block_size, counter);
         HIP_TRY(hipEventRecord(ev_end, helper));
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<false>, dim3(glob_waves), dim3(64), 0, st, d_stream, stream_len,
-                           d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb, counter);
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<false>, dim3(glob_waves), dim3(64), 0, st, w, block_size, counter);
         HIP_TRY(hipStreamWaitEvent(st, ev_end, 0));
     } else if (lds_waves) {
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, st, d_stream,
-                           stream_len, d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb, counter);
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, st, w, block_size, counter);
     } else
 #else
     if (getenv("SNAPPY_HIP_DECOMPRESS_VARIANT") && env_int("SNAPPY_HIP_DECOMPRESS_VARIANT", kDefaultDecompressVariant) != kDefaultDecompressVariant) {
@@ -816,12 +810,71 @@ int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, c
 #endif
     {
         const uint32_t glob = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nb, k2_cap), resident);
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<false>, dim3(glob), dim3(64), 0, st, d_stream, stream_len,
-                           d_block_offsets, total_len, block_size, d_out, d_status, (uint32_t)nb, counter);
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<false>, dim3(glob), dim3(64), 0, st, w, block_size, counter);
     }
     const hipError_t launched = hipGetLastError();
     if (int rc = work_counter_launched(wc, st)) return rc;       // after the join: the event covers both kernels
     HIP_TRY(launched);
+    return SNAPPY_HIP_OK;
+}
+
+static int check_stream(const void* d_stream, const void* d_block_offsets, uint64_t total_len, uint32_t block_size, const void* d_out,
+                        const void* d_status)
+{
+    if (!block_size_ok(block_size)) return fail(SNAPPY_HIP_ERR_ARG, "block_size must be 1..65535");
+    if (total_len && (!d_stream || !d_block_offsets || !d_out || !d_status)) return fail(SNAPPY_HIP_ERR_ARG, "null device pointer");
+    if (snappy_hip_num_blocks(total_len, block_size) > 0x7fffffffull) return fail(SNAPPY_HIP_ERR_ARG, "too many blocks");
+    return SNAPPY_HIP_OK;
+}
+
+int snappy_hip_decompress_blocks(const uint8_t* d_stream, uint64_t stream_len, const uint64_t* d_block_offsets,
+                                 uint64_t total_len, uint32_t block_size, uint8_t* d_out, uint32_t* d_status, void* stream)
+{
+    if (total_len == 0) return SNAPPY_HIP_OK;
+    if (int rc = check_stream(d_stream, d_block_offsets, total_len, block_size, d_out, d_status)) return rc;
+    snappy_hip::K2Batch w{};
+    w.count = 1;
+    w.first_block[0] = 0;
+    w.first_block[1] = (uint32_t)snappy_hip_num_blocks(total_len, block_size);
+    w.stream[0] = d_stream;
+    w.stream_len[0] = stream_len;
+    w.block_offsets[0] = d_block_offsets;
+    w.total_len[0] = total_len;
+    w.out[0] = d_out;
+    w.status[0] = d_status;
+    return launch_decompress(w, block_size, stream);
+}
+
+int snappy_hip_decompress_blocks_batch(const struct snappy_hip_decompress_item* items, uint32_t count, uint32_t block_size, void* stream)
+{
+    if (!items && count) return fail(SNAPPY_HIP_ERR_ARG, "null item array");
+    // empty streams are skipped; a launch takes at most kMaxBatch non-empty ones, so longer lists go out in groups
+    uint32_t i = 0;
+    while (i < count) {
+        snappy_hip::K2Batch w{};
+        uint64_t blocks = 0;
+        while (i < count && w.count < snappy_hip::kMaxBatch) {
+            const snappy_hip_decompress_item& it = items[i];
+            if (int rc = check_stream(it.d_stream, it.d_block_offsets, it.total_len, block_size, it.d_out, it.d_status)) return rc;
+            const uint64_t nb = snappy_hip_num_blocks(it.total_len, block_size);
+            if (nb) {
+                if (blocks + nb > 0x7fffffffull) break;
+                w.first_block[w.count] = (uint32_t)blocks;
+                w.stream[w.count] = static_cast<const uint8_t*>(it.d_stream);
+                w.stream_len[w.count] = it.stream_len;
+                w.block_offsets[w.count] = static_cast<const uint64_t*>(it.d_block_offsets);
+                w.total_len[w.count] = it.total_len;
+                w.out[w.count] = static_cast<uint8_t*>(it.d_out);
+                w.status[w.count] = static_cast<uint32_t*>(it.d_status);
+                blocks += nb;
+                ++w.count;
+            }
+            ++i;
+        }
+        w.first_block[w.count] = (uint32_t)blocks;
+        if (w.count)
+            if (int rc = launch_decompress(w, block_size, stream)) return rc;
+    }
     return SNAPPY_HIP_OK;
 }
 

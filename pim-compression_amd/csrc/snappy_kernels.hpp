@@ -1539,27 +1539,47 @@ __device__ __forceinline__ void k2_fast_elements(uint32_t lenv, uint32_t advv, u
 #undef K2_STORE_DEFERRED
 
 // amdgpu_num_sgpr: measured on gfx950, the 81st SGPR costs the eighth wavefront per SIMD (8.3 -> 9.0 ms per container).
+// One K2 launch can serve several streams (their own block offsets, output and status arrays; one block size): the
+// persistent wavefronts draw GLOBAL block numbers and map them to (stream, block), so a batch has one tail instead of one
+// per stream -- the decode-side twin of K1Batch.  Passed by value; the kernel argument segment is read with scalar loads.
+struct K2Batch {
+    uint32_t count;
+    uint32_t first_block[kMaxBatch + 1];   // first_block[count] = total number of blocks
+    const uint8_t* stream[kMaxBatch];
+    uint64_t stream_len[kMaxBatch];
+    const uint64_t* block_offsets[kMaxBatch];
+    uint64_t total_len[kMaxBatch];
+    uint8_t* out[kMaxBatch];
+    uint32_t* status[kMaxBatch];
+};
+
 template <bool kLdsWindow>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decompress_blocks_kernel(const uint8_t* __restrict__ stream, uint64_t stream_len,
-                                                               const uint64_t* __restrict__ block_offsets,
-                                                               uint64_t total_len, uint32_t block_size, uint8_t* out,
-                                                               uint32_t* __restrict__ status, uint32_t num_blocks,
-                                                               uint32_t* next_block)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decompress_blocks_kernel(const K2Batch w, uint32_t block_size,
+                                                                                                    uint32_t* next_block)
 {
     HIP_DYNAMIC_SHARED(uint8_t, lds_win)   // kLdsWindow: block_size rounded up to 16; dynamic LDS starts 16-byte aligned
     const uint32_t lane = threadIdx.x;
+    const uint32_t num_blocks = w.first_block[w.count];
 
     // Persistent: wavefronts draw blocks from *next_block (zeroed per launch), so the LDS-window form and the
     // global-window form can run concurrently on one stream of blocks and balance themselves.
     for (;;) {
         uint32_t drawn = 0;
         if (lane == 0) drawn = atomicAdd(next_block, 1u);
-        const uint32_t b = uni(drawn);
-        if (b >= num_blocks) break;
+        const uint32_t gb = uni(drawn);
+        if (gb >= num_blocks) break;
+        uint32_t c = 0;
+        while (c + 1 < w.count && gb >= w.first_block[c + 1]) ++c;
+        const uint32_t b = gb - w.first_block[c];
+        const uint8_t* __restrict__ stream = w.stream[c];
+        const uint64_t stream_len = w.stream_len[c];
+        const uint64_t* __restrict__ block_offsets = w.block_offsets[c];
+        const uint64_t total_len = w.total_len[c];
+        uint32_t* __restrict__ status = w.status[c];
         const uint64_t ostart = (uint64_t)b * block_size;
         const uint64_t oleft = total_len - ostart;
         const uint32_t out_len = (oleft < block_size) ? (uint32_t)oleft : block_size;
-        uint8_t* dst = out + ostart;
+        uint8_t* dst = w.out[c] + ostart;
         uint8_t* win = kLdsWindow ? lds_win : dst;
 
         uint32_t st = kBlockOk;

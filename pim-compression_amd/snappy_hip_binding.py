@@ -84,6 +84,8 @@ def lib():
         L.snappy_hip_compact.argtypes = [vp, u32, vp, u64, u32, vp, vp, vp, vp]
         L.snappy_hip_index_streams.restype = ctypes.c_int
         L.snappy_hip_index_streams.argtypes = [vp, u32, vp]
+        L.snappy_hip_decompress_blocks_batch.restype = ctypes.c_int
+        L.snappy_hip_decompress_blocks_batch.argtypes = [vp, u32, u32, vp]
         L.snappy_hip_verify_index.restype = ctypes.c_int
         L.snappy_hip_verify_index.argtypes = [vp, u32, vp]
         L.snappy_hip_decompress_blocks.restype = ctypes.c_int
@@ -261,6 +263,23 @@ def decompress_blocks(d_stream, stream_len, d_block_offsets, total_len, block_si
     _check(lib().snappy_hip_decompress_blocks(d_stream.data_ptr(), stream_len, d_block_offsets.data_ptr(), total_len,
                                               block_size, d_out.data_ptr(), d_status.data_ptr(), _stream_handle(torch)),
            "snappy_hip_decompress_blocks")
+
+
+class _DecompressItem(ctypes.Structure):        # struct snappy_hip_decompress_item
+    _fields_ = [("d_stream", ctypes.c_void_p), ("stream_len", ctypes.c_uint64), ("d_block_offsets", ctypes.c_void_p),
+                ("total_len", ctypes.c_uint64), ("d_out", ctypes.c_void_p), ("d_status", ctypes.c_void_p)]
+
+
+def decompress_blocks_batch(jobs, block_size):
+    """K2 over several streams in one launch.  jobs: list of (d_stream, stream_len, d_block_offsets, total_len, d_out, d_status)."""
+    import torch
+    if not jobs:
+        return
+    items = (_DecompressItem * len(jobs))()
+    for k, (d_stream, slen, d_off, total, d_out, d_status) in enumerate(jobs):
+        items[k] = _DecompressItem(d_stream.data_ptr(), slen, d_off.data_ptr(), total, d_out.data_ptr(), d_status.data_ptr())
+    _check(lib().snappy_hip_decompress_blocks_batch(ctypes.cast(items, ctypes.c_void_p), len(jobs), block_size,
+                                                    _stream_handle(torch)), "snappy_hip_decompress_blocks_batch")
 
 
 def decompress_resident(d_stream, stream_len=None):

@@ -343,13 +343,21 @@ int emu_decompress_variant(const uint8_t* stream, uint64_t stream_len, uint32_t 
     if (result[0] != 0 || result[1] != nb) return 1;
     std::vector<uint32_t> status(nb, 9);
     uint32_t k2_counter = 0;
+    snappy_hip::K2Batch kb{};
+    kb.count = 1;
+    kb.first_block[0] = 0;
+    kb.first_block[1] = nb;
+    kb.stream[0] = stream;
+    kb.stream_len[0] = stream_len;
+    kb.block_offsets[0] = boff.data();
+    kb.total_len[0] = total_len;
+    kb.out[0] = out;
+    kb.status[0] = status.data();
     emu::launch(nb < 3 ? nb : 3, 64, [&] {
         if (variant == 0)
-            snappy_hip::decompress_blocks_kernel<true>(stream, stream_len, boff.data(), total_len, block_size, out, status.data(), nb,
-                                                       &k2_counter);
+            snappy_hip::decompress_blocks_kernel<true>(kb, block_size, &k2_counter);
         else
-            snappy_hip::decompress_blocks_kernel<false>(stream, stream_len, boff.data(), total_len, block_size, out, status.data(), nb,
-                                                        &k2_counter);
+            snappy_hip::decompress_blocks_kernel<false>(kb, block_size, &k2_counter);
     });
     for (uint32_t i = 0; i < nb; ++i)
         if (status[i] != 0) return 1;

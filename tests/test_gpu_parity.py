@@ -402,6 +402,45 @@ def test_batched_launch_matches_per_container_oracle(shb):
                 assert bytes(out[:slen].cpu().numpy()) == oracle.compress(data, bs, threads=4), (bs, n)
 
 
+def test_batched_decode_launch_matches_per_stream(shb):
+    """snappy_hip_decompress_blocks_batch: several streams of different lengths (one empty) decoded by one launch, each
+    into its own output and status arrays, equal the plaintexts; a corrupt block in one stream is reported in that stream's
+    status only."""
+    import torch
+    text = golden_bytes("plrabn12.txt")
+    datas = [golden_bytes("world192.txt"), b"", datagen.text_random_interleave(text, 500_003), datagen.records(70_001),
+             datagen.random_bytes(33_000)]
+    bs = 4096
+    streams = [oracle.compress(d, bs) for d in datas]
+    bad = bytearray(streams[3])
+    at = list(oracle.index_blocks(streams[3]))[5] + 4          # first element of block 5 becomes "copy 64 bytes from 65535 back"
+    bad[at:at + 3] = bytes([0xFE, 0xFF, 0xFF])
+    streams.append(bytes(bad))
+    datas.append(datas[3])
+    jobs, keep = [], []
+    for d, s in zip(datas, streams):
+        total, got_bs, hdr = shb.parse_header(s[:10])
+        nb = shb.num_blocks(total, got_bs)
+        offs = np.zeros(max(nb, 1), dtype=np.int64)
+        at = hdr
+        for i in range(nb):
+            offs[i] = at
+            at += 4 + int.from_bytes(s[at:at + 4], "little")
+        d_stream, d_offs = to_dev(s), torch.from_numpy(offs).cuda()
+        d_out = torch.zeros(total + 16, dtype=torch.uint8, device="cuda")
+        d_status = torch.full((max(nb, 1),), 7, dtype=torch.int32, device="cuda")
+        jobs.append((d_stream, len(s), d_offs, total, d_out, d_status))
+        keep.append((d, nb))
+    shb.decompress_blocks_batch(jobs, bs)
+    torch.cuda.synchronize()
+    for k, ((d, nb), job) in enumerate(zip(keep, jobs)):
+        out, status = bytes(job[4][:len(d)].cpu().numpy()), job[5][:nb].cpu().numpy()
+        if k < len(jobs) - 1:
+            assert out == d and (status == 0).all(), k
+        else:
+            assert status[5] != 0 and (np.delete(status, 5) == 0).all()              # the corrupt block, and only that one
+
+
 def test_compress_without_scratch_uses_lds_table_kernel(shb):
     import torch
     data = golden_bytes("world192.txt")
