@@ -114,7 +114,7 @@ def build_inputs(shb, torch, workload, container_ids, container_len):
 class Batch:
     """Device-resident containers + the buffers one step needs."""
 
-    def __init__(self, shb, torch, inputs):
+    def __init__(self, shb, torch, inputs, groups=1):
         self.shb, self.torch = shb, torch
         self.inputs = inputs
         self.count = len(inputs)
@@ -140,6 +140,9 @@ class Batch:
         self.d_meta = torch.zeros(3 * max(1, self.count), dtype=torch.int64, device="cuda")   # stream_len, result[0..1]
         self.fallback_walks = 0
         self.steps_run = 0
+        self.groups = max(1, min(groups, self.count))
+        self.side_streams = [torch.cuda.Stream() for _ in range(2)]
+        self.group_done = [torch.cuda.Event() for _ in range(self.groups)]
 
     def _timed(self, key, record, fn):
         if not record:
@@ -153,35 +156,55 @@ class Batch:
         self.kernel_events[key].append((e0, e1))
 
     def step(self, record=False):
+        """Everything is enqueued without a host round trip: the stream lengths stay on the device (the decoder reads them
+        there), and the containers go through in `groups` launches so that the decode of group g (second stream) runs
+        underneath the compression of group g+1.  The host reads the index check results once, at the end."""
         shb, torch = self.shb, self.torch
         if not self.count:
             return
         self.steps_run += 1
-        # ---- compress: ONE K1 launch over every container of the rank, then framing per container ----
-        jobs = [(d_in, ln, ws) for (d_in, ln), ws in zip(self.inputs, self.wss)]
-        self._timed("compress", record, lambda: shb.compress_blocks_batch(jobs, scratch_ws=self.wss[0]))
-        for i in range(self.count):
-            shb.compact(self.n[i], self.wss[i], self.streams[i])
-            at = STREAM_DESC_BYTES * i + 8                   # descriptor field stream_len
-            self.descs[at:at + 8].copy_(self.wss[i].stream_len.view(torch.uint8), non_blocking=True)
-            self.d_meta[3 * i:3 * i + 1].copy_(self.wss[i].stream_len, non_blocking=True)
-        # ---- index: the compressor's offsets, checked link by link against the size chain of each stream ----
-        shb.verify_index(self.descs, self.count)
-        self.d_meta.view(self.count if self.count else 1, 3)[:, 1:3].copy_(self.results.view(-1, 2)[:self.count])
-        meta = self.d_meta.cpu().tolist()                     # the decoder's launch needs the lengths on the host
+        main = torch.cuda.current_stream()
+        bounds = [(self.count * g) // self.groups for g in range(self.groups + 1)]
+        for g in range(self.groups):
+            lo, hi = bounds[g], bounds[g + 1]
+            if lo == hi:
+                continue
+            # ---- compress: ONE K1 launch over the group's containers, then framing per container ----
+            jobs = [(self.inputs[i][0], self.n[i], self.wss[i]) for i in range(lo, hi)]
+            self._timed("compress", record, lambda: shb.compress_blocks_batch(jobs, scratch_ws=self.wss[0]))
+            for i in range(lo, hi):
+                shb.compact(self.n[i], self.wss[i], self.streams[i])
+                at = STREAM_DESC_BYTES * i + 8                   # descriptor field stream_len
+                self.descs[at:at + 8].copy_(self.wss[i].stream_len.view(torch.uint8), non_blocking=True)
+                self.d_meta[3 * i:3 * i + 1].copy_(self.wss[i].stream_len, non_blocking=True)
+            # ---- index: the compressor's offsets, checked link by link against the size chain of each stream ----
+            shb.verify_index(self.descs[STREAM_DESC_BYTES * lo:STREAM_DESC_BYTES * hi], hi - lo)
+            # ---- decompress: ONE K2 launch over the group's streams, beside the next group's K1 ----
+            djobs = [(self.streams[i], self.wss[i].stream_len, self.wss[i].offsets, self.n[i], self.outs[i], self.status[i])
+                     for i in range(lo, hi)]
+            last = g == self.groups - 1
+            side = main if last else self.side_streams[g % len(self.side_streams)]
+            if not last:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._timed("decompress", record, lambda: shb.decompress_blocks_batch(djobs, BLOCK_SIZE))
+            if not last:
+                self.group_done[g].record(side)
+        for g in range(self.groups - 1):
+            main.wait_event(self.group_done[g])
+        self.d_meta.view(self.count, 3)[:, 1:3].copy_(self.results.view(-1, 2)[:self.count])
+        meta = self.d_meta.cpu().tolist()                         # the only host read of the step, after everything is enqueued
         self.stream_lens = [int(meta[3 * i]) for i in range(self.count)]
         for i in range(self.count):
             if meta[3 * i + 1] != 0 or meta[3 * i + 2] != self.nb[i]:
-                # not expected for our own streams: fall back to the serial walk of the chain
+                # not expected for our own streams: walk the chain serially and decode that stream again
                 self.fallback_walks += 1
                 one = self.descs[STREAM_DESC_BYTES * i:STREAM_DESC_BYTES * (i + 1)]
                 shb.index_streams(one, 1)
                 if self.results[2 * i:2 * i + 2].cpu().tolist() != [0, self.nb[i]]:
                     raise RuntimeError(f"container {i}: the size chain of the compressed stream is broken")
-        # ---- decompress: ONE K2 launch over every stream of the rank ----
-        jobs = [(self.streams[i], self.stream_lens[i], self.wss[i].offsets, self.n[i], self.outs[i], self.status[i])
-                for i in range(self.count)]
-        self._timed("decompress", record, lambda: shb.decompress_blocks_batch(jobs, BLOCK_SIZE))
+                shb.decompress_blocks(self.streams[i], self.stream_lens[i], self.wss[i].offsets, self.n[i], BLOCK_SIZE, self.outs[i],
+                                      self.status[i])
 
     def verify(self):
         """Outside the timed region: every container round-trips bit-exactly through the stream alone (serial walk of the
@@ -350,6 +373,9 @@ def main():
                     choices=("silesia_mix", "dickens_like", "mozilla_like", "spamfile_like"),
                     help="silesia_mix = the 8 GiB batch (BASELINE configs[4]); the others time one stand-in file of "
                          "configs[2]/[3] on one GPU")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="launch groups per step: the decode of group g runs on a second stream underneath the compression of "
+                         "group g+1 (1 = strictly compress-all then decompress-all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -380,7 +406,7 @@ def main():
 
     n = args.container_mib << 20
     plan = [0] if single_file else shard_plan(rank, world, args.containers, args.scaling)
-    batch = Batch(shb, torch, build_inputs(shb, torch, args.workload, plan, n))
+    batch = Batch(shb, torch, build_inputs(shb, torch, args.workload, plan, n), groups=args.groups)
     ok = batch.verify()
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and batch.count
     gpu_stream0 = bytes(batch.streams[0][:batch.stream_lens[0]].cpu().numpy()) if want_cpu else b""
@@ -413,11 +439,12 @@ def main():
     if rank == 0:
         c_ms = batch.kernel_ms("compress")
         d_ms = batch.kernel_ms("decompress")
-        u = sum(batch.n)                                      # one K1 launch covers every container of the rank
-        c = sum(batch.stream_lens)
+        launches = max(1, batch.groups)                       # K1 / K2 launches per step (equal groups of containers)
+        u = sum(batch.n) / launches                           # uncompressed bytes per launch
+        c = sum(batch.stream_lens) / launches
         algo_bytes = u + c                                    # read plaintext once, write compressed once
         achieved = algo_bytes / (c_ms * 1e-3) / 1e9
-        d_algo = u + c                                        # one K2 launch covers every stream of the rank
+        d_algo = u + c
         pmc = load_pmc_traffic()
         share = batch.lds_share()
         traffic = None
@@ -447,7 +474,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload,
                        "containers_this_rank": batch.count, "container_bytes": batch.n[0] if batch.count else 0,
-                       "block_size": BLOCK_SIZE,
+                       "block_size": BLOCK_SIZE, "launch_groups_per_step": batch.groups,
                        "parallelism": f"whole containers dealt over {world} GPU(s), no collective"},
             "roundtrip_bit_exact": bool(ok),
             "space_saving": round(1.0 - tot_comp / tot_bytes, 6),

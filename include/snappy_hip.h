@@ -224,7 +224,9 @@ int snappy_hip_decompress_blocks(const uint8_t *d_stream, uint64_t stream_len, c
  */
 struct snappy_hip_decompress_item {
     const void *d_stream;          /* device: the framed stream (its header)                */
-    uint64_t stream_len;
+    uint64_t stream_len;           /* bytes; ignored when d_stream_len is given             */
+    const void *d_stream_len;      /* device u64 or NULL: the length as left by snappy_hip_compact (*d_stream_len), so that a
+                                      compress -> decompress chain needs no host round trip for it */
     const void *d_block_offsets;   /* device: num_blocks(total_len) u64                     */
     uint64_t total_len;            /* uncompressed length from the header                   */
     void *d_out;                   /* device: total_len bytes                               */

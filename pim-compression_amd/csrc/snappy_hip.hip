@@ -862,6 +862,7 @@ int snappy_hip_decompress_blocks_batch(const struct snappy_hip_decompress_item* 
                 w.first_block[w.count] = (uint32_t)blocks;
                 w.stream[w.count] = static_cast<const uint8_t*>(it.d_stream);
                 w.stream_len[w.count] = it.stream_len;
+                w.stream_len_dev[w.count] = static_cast<const uint64_t*>(it.d_stream_len);
                 w.block_offsets[w.count] = static_cast<const uint64_t*>(it.d_block_offsets);
                 w.total_len[w.count] = it.total_len;
                 w.out[w.count] = static_cast<uint8_t*>(it.d_out);

@@ -1547,6 +1547,7 @@ struct K2Batch {
     uint32_t first_block[kMaxBatch + 1];   // first_block[count] = total number of blocks
     const uint8_t* stream[kMaxBatch];
     uint64_t stream_len[kMaxBatch];
+    const uint64_t* stream_len_dev[kMaxBatch];   // when not null: the length is read from the device (no host round trip)
     const uint64_t* block_offsets[kMaxBatch];
     uint64_t total_len[kMaxBatch];
     uint8_t* out[kMaxBatch];
@@ -1572,7 +1573,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
         while (c + 1 < w.count && gb >= w.first_block[c + 1]) ++c;
         const uint32_t b = gb - w.first_block[c];
         const uint8_t* __restrict__ stream = w.stream[c];
-        const uint64_t stream_len = w.stream_len[c];
+        const uint64_t* len_dev = w.stream_len_dev[c];
+        const uint64_t stream_len = len_dev ? uld64(reinterpret_cast<const uint8_t*>(len_dev)) : w.stream_len[c];
         const uint64_t* __restrict__ block_offsets = w.block_offsets[c];
         const uint64_t total_len = w.total_len[c];
         uint32_t* __restrict__ status = w.status[c];

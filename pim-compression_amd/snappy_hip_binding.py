@@ -266,18 +266,22 @@ def decompress_blocks(d_stream, stream_len, d_block_offsets, total_len, block_si
 
 
 class _DecompressItem(ctypes.Structure):        # struct snappy_hip_decompress_item
-    _fields_ = [("d_stream", ctypes.c_void_p), ("stream_len", ctypes.c_uint64), ("d_block_offsets", ctypes.c_void_p),
-                ("total_len", ctypes.c_uint64), ("d_out", ctypes.c_void_p), ("d_status", ctypes.c_void_p)]
+    _fields_ = [("d_stream", ctypes.c_void_p), ("stream_len", ctypes.c_uint64), ("d_stream_len", ctypes.c_void_p),
+                ("d_block_offsets", ctypes.c_void_p), ("total_len", ctypes.c_uint64), ("d_out", ctypes.c_void_p),
+                ("d_status", ctypes.c_void_p)]
 
 
 def decompress_blocks_batch(jobs, block_size):
-    """K2 over several streams in one launch.  jobs: list of (d_stream, stream_len, d_block_offsets, total_len, d_out, d_status)."""
+    """K2 over several streams in one launch.  jobs: list of (d_stream, stream_len, d_block_offsets, total_len, d_out, d_status);
+    stream_len is an int, or a device int64 tensor of one element (the length stays on the device)."""
     import torch
     if not jobs:
         return
     items = (_DecompressItem * len(jobs))()
     for k, (d_stream, slen, d_off, total, d_out, d_status) in enumerate(jobs):
-        items[k] = _DecompressItem(d_stream.data_ptr(), slen, d_off.data_ptr(), total, d_out.data_ptr(), d_status.data_ptr())
+        on_dev = hasattr(slen, "data_ptr")
+        items[k] = _DecompressItem(d_stream.data_ptr(), 0 if on_dev else slen, slen.data_ptr() if on_dev else None, d_off.data_ptr(),
+                                   total, d_out.data_ptr(), d_status.data_ptr())
     _check(lib().snappy_hip_decompress_blocks_batch(ctypes.cast(items, ctypes.c_void_p), len(jobs), block_size,
                                                     _stream_handle(torch)), "snappy_hip_decompress_blocks_batch")
 
