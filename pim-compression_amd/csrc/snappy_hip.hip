@@ -797,20 +797,26 @@ static int launch_decompress(const snappy_hip::K2Batch& w, uint32_t block_size, 
         HIP_TRY(hipStreamWaitEvent(helper, ev_begin, 0));
         hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, helper, w, block_size, counter);
         HIP_TRY(hipEventRecord(ev_end, helper));
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<false>, dim3(glob_waves), dim3(64), 0, st, w, block_size, counter);
+        hipLaunchKernelGGL((snappy_hip::decompress_blocks_kernel<false, true>), dim3(glob_waves), dim3(64), 0, st, w, block_size, counter);
         HIP_TRY(hipStreamWaitEvent(st, ev_end, 0));
     } else if (lds_waves) {
         hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, st, w, block_size, counter);
     } else
 #else
-    if (getenv("SNAPPY_HIP_DECOMPRESS_VARIANT") && env_int("SNAPPY_HIP_DECOMPRESS_VARIANT", kDefaultDecompressVariant) != kDefaultDecompressVariant) {
+    if ((getenv("SNAPPY_HIP_DECOMPRESS_VARIANT") && env_int("SNAPPY_HIP_DECOMPRESS_VARIANT", kDefaultDecompressVariant) != kDefaultDecompressVariant) ||
+        (getenv("SNAPPY_HIP_K2_BATCH") && !env_int("SNAPPY_HIP_K2_BATCH", 1))) {
         (void)work_counter_launched(wc, st);
-        return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_DECOMPRESS_VARIANT selects an ablation kernel; this library was built without them");
+        return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_DECOMPRESS_VARIANT / SNAPPY_HIP_K2_BATCH select an ablation kernel; this library was built without them");
     }
 #endif
     {
         const uint32_t glob = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nb, k2_cap), resident);
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<false>, dim3(glob), dim3(64), 0, st, w, block_size, counter);
+#ifdef SNAPPY_ABLATION
+        if (!env_int("SNAPPY_HIP_K2_BATCH", 1))       // round 1's element-at-a-time loop
+            hipLaunchKernelGGL((snappy_hip::decompress_blocks_kernel<false, false>), dim3(glob), dim3(64), 0, st, w, block_size, counter);
+        else
+#endif
+            hipLaunchKernelGGL((snappy_hip::decompress_blocks_kernel<false, true>), dim3(glob), dim3(64), 0, st, w, block_size, counter);
     }
     const hipError_t launched = hipGetLastError();
     if (int rc = work_counter_launched(wc, st)) return rc;       // after the join: the event covers both kernels
@@ -1117,7 +1123,7 @@ int warm_up_device()
     HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel<64, 2, 1>)));
     HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_lds_table_kernel<64, 2>)));
     HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::gather_slots_kernel)));
-    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel<false>)));
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel<false, true>)));
     CoRunResources* cr = nullptr;
     if (int rc = corun_resources(&cr)) return rc;
     WorkCounter c;

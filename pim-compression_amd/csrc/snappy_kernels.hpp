@@ -1539,6 +1539,67 @@ __device__ __forceinline__ void k2_fast_elements(uint32_t lenv, uint32_t advv, u
 #undef K2_STORE_DEFERRED
 
 // amdgpu_num_sgpr: measured on gfx950, the 81st SGPR costs the eighth wavefront per SIMD (8.3 -> 9.0 ms per container).
+// ---------------------------------------------------------------------------
+// K2, per-window batch (default).  PMC on the element-at-a-time loop showed K2 bound by the scalar unit (3.7e9 SALU
+// instructions per 2 GiB container, 83 % of what the chip's scalar units can issue in the kernel's time, against 2.4e9 VALU).
+// Here the only per-element scalar work left is following the element chain (v_readlane + add + compare + branch); everything
+// else is done for all elements of a 64-byte window at once:
+//   * output offsets: exclusive prefix sum of the elements' lengths (DPP row scans), one bounds check for the window;
+//   * literals: every payload byte of the window finds its element (the last element start at or below its lane) and its
+//     output position with one ds_bpermute, ONE byte store for all literals of the window;
+//   * copies whose source lies wholly before this window's output and does not overlap their destination (the common case
+//     in text): one LANE per copy, unaligned dword load / store steps, all such copies of the window in parallel;
+//   * the other copies (source inside this window's output, or overlapping, or shorter than 4): in element order, one
+//     predicated byte load + store each, as before -- loads issued after the stores above see them (same-wavefront
+//     global_* operations complete in order; tests/test_abi_symbols.py keeps flat_* out of this kernel).
+// Same strictness as the element loop: any invalid element, overrun of the block's output, zero offset or reach before
+// the block start makes the block invalid.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
+{
+#ifdef SNAPPY_EMU
+    for (uint32_t d = 1; d < kWave; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, (int)d);
+        if (lane >= d) v += t;
+    }
+#else
+    (void)lane;
+    // Hillis-Steele inside each row of 16 lanes (row_shr:1,2,4,8; lanes without a source keep the 0 of `old`), then the row
+    // totals travel up: lane 15 of rows 0 and 2 into rows 1 and 3, lane 31 into rows 2 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+#endif
+    return v;
+}
+
+// Follow the element chain of one window: E collects the lanes where an element starts, s ends at or beyond wlim.
+// advv = compressed bytes the element that starts at a lane takes (64 for a start predecode rejected: ends the walk).
+__device__ __forceinline__ void k2_chain_walk(uint32_t advv, uint32_t wlim, uint32_t& s, unsigned long long& E)
+{
+#ifdef SNAPPY_EMU
+    do {
+        E |= 1ull << s;
+        s += (uint32_t)__builtin_amdgcn_readlane((int)advv, (int)s);
+    } while (s < wlim);
+#else
+    uint32_t a;
+    asm volatile(
+        "1:\n"
+        "  s_bitset1_b64 %[E], %[s]\n"
+        "  v_readlane_b32 %[a], %[advv], %[s]\n"
+        "  s_add_u32 %[s], %[s], %[a]\n"
+        "  s_cmp_lt_u32 %[s], %[wlim]\n"
+        "  s_cbranch_scc1 1b\n"
+        : [s] "+s"(s), [E] "+s"(E), [a] "=&s"(a)
+        : [advv] "v"(advv), [wlim] "s"(wlim)
+        : "scc");
+#endif
+}
+
 // One K2 launch can serve several streams (their own block offsets, output and status arrays; one block size): the
 // persistent wavefronts draw GLOBAL block numbers and map them to (stream, block), so a batch has one tail instead of one
 // per stream -- the decode-side twin of K1Batch.  Passed by value; the kernel argument segment is read with scalar loads.
@@ -1554,7 +1615,7 @@ struct K2Batch {
     uint32_t* status[kMaxBatch];
 };
 
-template <bool kLdsWindow>
+template <bool kLdsWindow, bool kBatch = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decompress_blocks_kernel(const K2Batch w, uint32_t block_size,
                                                                                                     uint32_t* next_block)
 {
@@ -1600,22 +1661,155 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
         uint32_t cp = 0, op = 0;    // compressed / output cursors
         uint64_t w0 = 0;
         WindowLoad next = {0, 64};  // prefetch of the following 64 bytes (W1), shift applied at use
+        WindowLoad next2 = {0, 64}; // batch form: the 64 bytes after those, so that W1 has arrived when a literal runs on into it
         bool have_window = false;
         while (st == kBlockOk && cp < csz) {                             // one iteration per 64-byte window
             if (!have_window || cp >= g + 128) {
                 g = cp & ~63u;
-                w0 = window_value(window_issue(src, (uint64_t)g + lane, avail));
+                const WindowLoad cur = window_issue(src, (uint64_t)g + lane, avail);
+                if constexpr (kBatch) {                                  // all three requests go out before the first is awaited
+                    next = window_issue(src, (uint64_t)g + 64 + lane, avail);
+                    next2 = window_issue(src, (uint64_t)g + 128 + lane, avail);
+                }
+                w0 = window_value(cur);
                 have_window = true;
             } else {                                                     // cp in [g+64, g+128): slide by 64
                 g += 64;
                 w0 = window_value(next);
+                if constexpr (kBatch) {
+                    next = next2;
+                    next2 = window_issue(src, (uint64_t)g + 128 + lane, avail);
+                }
             }
             uint32_t meta, offv;
             predecode(w0, g + lane, csz, meta, offv);
-            // issue the prefetch only after w0 has been consumed, so the wait for w0 cannot cover it
-            __builtin_amdgcn_sched_barrier(0);
-            next = window_issue(src, (uint64_t)g + 64 + lane, avail);    // stays in flight during this window
+            if constexpr (!kBatch) {
+                // issue the prefetch only after w0 has been consumed, so the wait for w0 cannot cover it
+                __builtin_amdgcn_sched_barrier(0);
+                next = window_issue(src, (uint64_t)g + 64 + lane, avail);    // stays in flight during this window
+            }
             const uint32_t wend = (csz < g + 64) ? csz : g + 64;
+            if constexpr (kBatch && !kLdsWindow) {
+                // ================= the whole window at once =================
+                const uint32_t wlim = wend - g;
+                const uint32_t e_type = meta & 3u, e_hdr = (meta >> 2) & 7u, e_len = meta >> 8;
+                const uint32_t advv = meta ? e_hdr + (e_type ? 0u : e_len) : 64u;
+                uint32_t s = cp - g;
+                unsigned long long E = 0;
+                k2_chain_walk(advv, wlim, s, E);
+                if (E & __ballot(meta == 0)) {                           // an element predecode rejected
+                    st = kBlockInvalid;
+                    break;
+                }
+                const bool is_e = __builtin_amdgcn_inverse_ballot_w64(E);
+                const uint32_t mylen = is_e ? e_len : 0u;
+                const uint32_t incl = wave_inclusive_scan(mylen, lane);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint32_t dstp = op + incl - mylen;                 // where this lane's element writes
+                const bool is_copy = is_e && e_type != 0;
+                if (op + total > out_len || __ballot(is_copy && (offv == 0 || offv > dstp))) {   // strict, cf. :167-173
+                    st = kBlockInvalid;
+                    break;
+                }
+                // ---- literals: a payload byte belongs to the last element that starts at or below its lane ----
+                {
+                    const uint32_t lo = (uint32_t)E, hi = (uint32_t)(E >> 32);
+                    const uint32_t mlo = lane >= 31u ? 0xffffffffu : ((2u << lane) - 1u);
+                    const uint32_t mhi = lane < 32u ? 0u : (lane == 63u ? 0xffffffffu : ((2u << (lane - 32u)) - 1u));
+                    const uint32_t blo = lo & mlo, bhi = hi & mhi;
+                    const bool any = (blo | bhi) != 0;
+                    const uint32_t em = bhi ? 63u - (uint32_t)__builtin_clz(bhi) : (blo ? 31u - (uint32_t)__builtin_clz(blo) : 0u);
+                    const uint32_t packed = (dstp - op) | (e_hdr << 16) | (e_type << 20);     // offsets inside a window are < 4096
+                    const uint32_t pk = (uint32_t)__shfl((int)packed, (int)em);
+                    const uint32_t pstart = em + ((pk >> 16) & 7u);
+                    if (any && ((pk >> 20) & 3u) == 0 && lane >= pstart && lane < wlim) win[op + (pk & 0xffffu) + lane - pstart] = (uint8_t)w0;
+                }
+                // a literal that runs on beyond the window is its last element: the next 64 bytes come from the prefetch
+                // registers, anything beyond straight from memory
+                {
+                    const uint32_t le = 63u - (uint32_t)__builtin_clzll(E);
+                    const uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)meta, (int)le);
+                    const uint32_t ps = le + ((lm >> 2) & 7u), pe = ps + (lm >> 8);
+                    if ((lm & 3u) == 0 && pe > 64u) {
+                        const uint32_t dbase = (uint32_t)__builtin_amdgcn_readlane((int)dstp, (int)le) - ps;   // byte at g + q goes to dbase + q
+                        WindowLoad nx = next;
+                        SNAPPY_PIN(nx.shift);                            // first use of the prefetch: wait here, not earlier
+                        const uint64_t w1 = window_value(nx);
+                        const uint32_t q = 64u + lane;
+                        if (q >= ps && q < pe) win[dbase + q] = (uint8_t)w1;
+                        if (pe > 128u) {
+                            const uint8_t* __restrict__ p = src + g + 128u;
+                            uint8_t* d = win + (uint32_t)(dbase + 128u);   // dbase may be "negative" (mod 2^32): add before widening
+                            const uint32_t rest = pe - 128u;
+                            uint32_t i = 4 * lane;
+                            for (; i + 4 <= rest; i += 4 * kWave) st32(d + i, ld32(p + i));
+                            for (; i < rest; ++i) d[i] = p[i];
+                        }
+                    }
+                }
+                // ---- copies.  A copy that does not overlap its own destination and is at least 4 bytes long can be done by ONE lane
+                //      in unaligned dword steps ("steppable"); every set of steppable copies whose sources lie wholly in finished
+                //      output is done together, four loads per lane in flight before the four stores.  Round 0: sources before
+                //      this window's output (any position in the window).  Later rounds: the first copy still to do, with every
+                //      other one whose source ends before that copy's destination -- all output below it is complete.  The rest
+                //      (overlapping, i.e. :174-181 replicating the last `off` bytes, or shorter than 4) go one at a time ----
+                {
+                    const bool steppable = is_copy && e_len >= 4u && offv >= e_len;
+                    const uint32_t src_end = dstp - offv + e_len;
+                    const unsigned long long STEP = __ballot(steppable);
+                    const uint8_t* sp = win + (dstp - offv);
+                    uint8_t* dp = win + dstp;
+                    unsigned long long rem = __ballot(is_copy);
+                    unsigned long long ready = rem & __ballot(steppable && src_end <= op);
+                    for (;;) {
+                        if (ready) {
+                            const bool mine = __builtin_amdgcn_inverse_ballot_w64(ready);
+                            // offsets beyond the copy's length are clamped to its last dword: those steps reload and rewrite that
+                            // dword (same bytes, same place), so the four loads and four stores need no predicate of their own
+                            if (mine) {
+                                const uint32_t last = e_len - 4u;
+                                {                                        // bytes 0..7: most copies of a text end here
+                                    const uint32_t o1 = 4u < last ? 4u : last;
+                                    const uint32_t v0 = ld32(sp), v1 = ld32(sp + o1);
+                                    st32(dp, v0);
+                                    st32(dp + o1, v1);
+                                }
+                                for (uint32_t base = 8u; base < e_len; base += 16u) {
+                                    const uint32_t o0 = base < last ? base : last, o1 = base + 4u < last ? base + 4u : last,
+                                                   o2 = base + 8u < last ? base + 8u : last, o3 = base + 12u < last ? base + 12u : last;
+                                    const uint32_t v0 = ld32(sp + o0), v1 = ld32(sp + o1), v2 = ld32(sp + o2), v3 = ld32(sp + o3);
+                                    st32(dp + o0, v0);
+                                    st32(dp + o1, v1);
+                                    st32(dp + o2, v2);
+                                    st32(dp + o3, v3);
+                                }
+                            }
+                            rem &= ~ready;
+                        }
+                        if (!rem) break;
+                        const uint32_t f = (uint32_t)__builtin_ctzll(rem);
+                        const uint32_t fd = (uint32_t)__builtin_amdgcn_readlane((int)dstp, (int)f);
+                        if ((STEP >> f) & 1ull) {
+                            ready = rem & __ballot(steppable && src_end <= fd);
+                            continue;
+                        }
+                        const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)e_len, (int)f);
+                        const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)offv, (int)f);
+                        uint32_t src_idx = lane;
+                        if (off < len) {                                 // overlap: lane % off (lane < 64, off < 64)
+                            const uint32_t q = (lane * kRecip16[off]) >> 16;
+                            src_idx = lane - q * off;
+                        }
+                        if (lane < len) win[fd + lane] = win[fd - off + src_idx];
+                        __builtin_amdgcn_wave_barrier();
+                        rem &= rem - 1;
+                        ready = 0;
+                    }
+                }
+                op += total;
+                cp = g + s;
+                continue;
+            }
 #ifndef SNAPPY_EMU
             // operands of the hand-scheduled loop: the pre-decoded fields one register each, the two classes as lane masks
             const uint32_t e_hdr = (meta >> 2) & 7u, e_len = meta >> 8;

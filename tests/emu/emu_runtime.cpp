@@ -356,6 +356,8 @@ int emu_decompress_variant(const uint8_t* stream, uint64_t stream_len, uint32_t 
     emu::launch(nb < 3 ? nb : 3, 64, [&] {
         if (variant == 0)
             snappy_hip::decompress_blocks_kernel<true>(kb, block_size, &k2_counter);
+        else if (variant == 3)
+            snappy_hip::decompress_blocks_kernel<false, true>(kb, block_size, &k2_counter);      // per-window batch
         else
             snappy_hip::decompress_blocks_kernel<false>(kb, block_size, &k2_counter);
     });

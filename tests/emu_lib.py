@@ -57,7 +57,7 @@ def compress(data, block_size=32768, variant=12503):   # the product default: bu
     return out[:got].tobytes()
 
 
-def decompress(stream, total_len, block_size, header_len, variant=1):
+def decompress(stream, total_len, block_size, header_len, variant=3):   # 3 = the product's per-window batch decoder
     a = np.frombuffer(stream, dtype=np.uint8).copy()
     out = np.zeros(max(total_len, 1) + 16, dtype=np.uint8)
     st = lib().emu_decompress_variant(a.ctypes.data, a.size, total_len, block_size, header_len, out.ctypes.data, variant)

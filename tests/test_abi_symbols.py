@@ -80,8 +80,8 @@ def test_k2_back_references_use_global_not_flat_instructions(tmp_path):
     asm = tmp_path / "device.s"
     subprocess.check_call([entry.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", str(asm)])
     text = asm.read_text()
-    m = re.search(r"^(_ZN10snappy_hip24decompress_blocks_kernelILb0EE\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
-    assert m, "decompress_blocks_kernel<false> not found in the device code"
+    m = re.search(r"^(_ZN10snappy_hip24decompress_blocks_kernelILb0ELb1EE\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
+    assert m, "decompress_blocks_kernel<false, true> (the per-window batch decoder) not found in the device code"
     body = m.group(2)
     assert len(re.findall(r"^\s*global_(?:load|store)", body, re.M)) >= 20
     assert re.findall(r"^\s*flat_\w+", body, re.M) == []

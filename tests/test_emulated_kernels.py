@@ -45,7 +45,7 @@ def test_emulated_long_runs_and_split_copies():
 
 # compress variant = kernel form + 100 * look-ahead code (1 = off, 2 = 4, 3 = 8, 4 = 16, 5 = 64 positions)
 # + 1000 for the masked form, + 2000 for the bulk form, + 10000 for the LDS slot filter (see emu_runtime.cpp)
-@pytest.mark.parametrize("cv,dv", [(6, 1), (2501, 1), (12503, 1),                                 # the shipped forms
+@pytest.mark.parametrize("cv,dv", [(6, 3), (2501, 3), (12503, 3),                                 # the shipped forms
                                    (1, 0), (4, 0), (5, 1), (103, 1), (403, 1), (1503, 1), (1501, 0),    # a sample of csrc/ablation/
                                    (2403, 1), (10503, 1), (22503, 1)])
 def test_emulated_other_variants(cv, dv):

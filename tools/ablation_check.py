@@ -38,6 +38,7 @@ VARIANTS = [
     {"SNAPPY_HIP_K1_AHEAD": "32", **TINY_HYBRID}, {"SNAPPY_HIP_K1_FILTER": "2"}, {"SNAPPY_HIP_K1_FILTER": "2", **TINY_HYBRID},
     # K2: output window in LDS, both forms concurrently
     {"SNAPPY_HIP_DECOMPRESS_VARIANT": "0"}, {"SNAPPY_HIP_DECOMPRESS_VARIANT": "2", "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"},
+    {"SNAPPY_HIP_K2_BATCH": "0"},
 ]
 
 

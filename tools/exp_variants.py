@@ -60,7 +60,7 @@ def main():
     boff = ws.offsets[:nb].contiguous()
     status = torch.empty(nb, dtype=torch.int32, device="cuda")
     out = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
-    for dv in ("1",):                            # "0" (LDS output window) exists in the ablation build only
+    for dv in ("1",):                            # "0" (round 1's element loop) exists in the ablation build only
         out.zero_()
         times = []
         for it in range(4):
@@ -70,7 +70,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1))
-        print(f"decompress variant {dv} best {min(times[1:]):8.3f} ms {n / min(times[1:]) / 1e6:8.2f} GB/s "
+        print(f"decompress batch={dv} best {min(times[1:]):8.3f} ms {n / min(times[1:]) / 1e6:8.2f} GB/s "
               f"ok={torch.equal(out[:n], d_in[:n])} bad_blocks={int((status != 0).sum())}")
 
 
