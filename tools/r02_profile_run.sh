@@ -8,13 +8,13 @@ mkdir -p $OUT
 PART=${1:-all}
 if [ "$PART" = all ] || [ "$PART" = bench ]; then
   timeout -k 10 500 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
-  ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_prof -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err )
+  ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_prof -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-preverify > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err )
   tail -c 600 $OUT/bench.json
 fi
 if [ "$PART" = all ] || [ "$PART" = workloads ]; then
   for w in dickens_like mozilla_like spamfile_like; do
     timeout -k 10 300 python bench.py --workload $w --steps 50 --warmup 5 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
-    ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -- python3 $ROOT/bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_${w}_under_rocprof.json 2> $OUT/prof_$w.err )
+    ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -- python3 $ROOT/bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline --no-preverify > $OUT/bench_${w}_under_rocprof.json 2> $OUT/prof_$w.err )
     python3 -c "import json;d=json.loads(open('$OUT/bench_$w.json').read().strip().splitlines()[-1]);print('$w',d['value'],d['ms_per_step'],d['compress_kernel_GBps'],d['decompress_kernel_GBps'])"
   done
 fi
