@@ -402,6 +402,52 @@ def test_batched_launch_matches_per_container_oracle(shb):
                 assert bytes(out[:slen].cpu().numpy()) == oracle.compress(data, bs, threads=4), (bs, n)
 
 
+def test_verify_index_on_device(shb):
+    """snappy_hip_verify_index on the GPU: the offsets snappy_hip_compact produced pass for every stream of a batch; a
+    candidate with one wrong entry, a candidate for a stream whose size field was changed, and a wrong stream length are
+    rejected -- and snappy_hip_index_streams then finds what verification accepted."""
+    import torch
+    text = golden_bytes("plrabn12.txt")
+    datas = [datagen.text_random_interleave(text, 700_001), golden_bytes("world192.txt"), datagen.records(300_000)]
+    bs = 4096
+    entries, keep = [], []
+    for d in datas:
+        n = len(d)
+        ws = shb.CompressWorkspace(n, bs)
+        d_stream = torch.empty(ws.stream_capacity(n) + 16, dtype=torch.uint8, device="cuda")
+        shb.compress_blocks(to_dev(d), n, ws)
+        shb.compact(n, ws, d_stream)
+        slen = int(ws.stream_len.item())
+        assert bytes(d_stream[:slen].cpu().numpy()) == oracle.compress(d, bs)
+        nb = shb.num_blocks(n, bs)
+        res = torch.full((2,), 7, dtype=torch.int32, device="cuda")
+        hdr = len(shb.write_header(n, bs))
+        entries.append(dict(stream=d_stream, stream_len=slen, block_offsets=ws.offsets, result=res, total_len=n, block_size=bs,
+                            header_len=hdr, num_blocks=nb))
+        keep.append((ws, d_stream, res, nb, slen))
+    descs = shb.make_stream_descs(entries)
+    shb.verify_index(descs, len(entries))
+    for ws, _, res, nb, _ in keep:
+        assert res.cpu().tolist() == [0, nb]
+    # one wrong entry in stream 1's candidate; a changed size field in stream 2; a wrong length for stream 0
+    keep[1][0].offsets[keep[1][3] // 2] += 1
+    at = int(keep[2][0].offsets[3].item())
+    keep[2][1][at] ^= 1
+    entries[0]["stream_len"] = keep[0][4] - 1
+    descs = shb.make_stream_descs(entries)
+    shb.verify_index(descs, len(entries))
+    for ws, _, res, nb, _ in keep:
+        st, links = res.cpu().tolist()
+        assert st != 0 and links < nb
+    # the serial walk agrees with the accepted candidate (stream 1, whose candidate was only perturbed after verification)
+    boff = torch.zeros(keep[1][3] + 1, dtype=torch.int64, device="cuda")
+    entries[1]["block_offsets"] = boff
+    shb.index_streams(shb.make_stream_descs([entries[1]]), 1)
+    good = keep[1][0].offsets.clone()
+    good[keep[1][3] // 2] -= 1
+    assert torch.equal(boff[:keep[1][3]], good[:keep[1][3]]) and keep[1][2].cpu().tolist() == [0, keep[1][3]]
+
+
 def test_batched_decode_launch_matches_per_stream(shb):
     """snappy_hip_decompress_blocks_batch: several streams of different lengths (one empty) decoded by one launch, each
     into its own output and status arrays, equal the plaintexts; a corrupt block in one stream is reported in that stream's
