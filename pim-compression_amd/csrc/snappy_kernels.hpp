@@ -700,6 +700,9 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
             uint32_t r = ip - win.base;
             if (r >= uni(st.cov_end)) st.template gather<true, true>(table, win, dup_scratch, r, kChunk, lane, n);
             unsigned long long stopm = st.dup | st.longm;
+#ifdef K1X_NO_STOPS       // timing experiment of tools/k1x_pmc.sh (wrong bytes on purpose; never defined in a product build)
+            stopm = 0;
+#endif
 
             bool need_single = true;
             if (stride <= 1 || !((stopm >> r) & 1ull)) {
@@ -818,7 +821,15 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
                 for (unsigned long long d = C & st.dup; d; d &= d - 1)                         // shared slots: in position order
                     State::commit(table, win, d & (~d + 1), lane);
 
+#ifdef K1X_NO_EMIT        // timing experiment of tools/k1x_pmc.sh (wrong bytes on purpose; never defined in a product build)
                 if (H) {
+                    op += 8;
+                    next_emit = win.base + ((why == 0) ? r : 64u - (uint32_t)__builtin_clzll(COV));
+                }
+                if (false) {
+#else
+                if (H) {
+#endif
                     // ---- emission ----
                     const uint32_t first_hit = (uint32_t)__builtin_ctzll(H);
                     const uint32_t last_end = (why == 0) ? r_end : 64u - (uint32_t)__builtin_clzll(COV);

@@ -13,6 +13,9 @@ import torch
 import silesia_mix
 import snappy_hip_binding as shb
 
+if os.environ.get("SNAPPY_PROF_LIB"):            # an experimental build of the library (timing experiments)
+    shb.LIB_PATH = os.environ["SNAPPY_PROF_LIB"]
+
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 n = mib << 20
