@@ -279,6 +279,27 @@ __device__ __forceinline__ void lds_and(lds_words_t p, uint32_t v)
 }
 #endif
 
+// unaligned dword access to LDS (gfx950 runs with unaligned DS access enabled, like its VMEM)
+#ifdef SNAPPY_EMU
+__device__ __forceinline__ uint32_t lds_ld32u(lds_bytes_t p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, (const void*)p, 4);
+    return v;
+}
+__device__ __forceinline__ void lds_st32u(lds_bytes_t p, uint32_t v) { __builtin_memcpy((void*)p, &v, 4); }
+#else
+typedef uint32_t __attribute__((aligned(1))) lds_u32_unaligned_t;
+__device__ __forceinline__ uint32_t lds_ld32u(lds_bytes_t p)
+{
+    return *reinterpret_cast<volatile __attribute__((address_space(3))) lds_u32_unaligned_t*>(p);
+}
+__device__ __forceinline__ void lds_st32u(lds_bytes_t p, uint32_t v)
+{
+    *reinterpret_cast<volatile __attribute__((address_space(3))) lds_u32_unaligned_t*>(p) = v;
+}
+#endif
+
 #ifdef SNAPPY_ABLATION
 }  // namespace snappy_hip
 #include "ablation/k1_tables.hpp"
@@ -1407,6 +1428,31 @@ __device__ __forceinline__ void predecode(uint64_t w, uint32_t pos, uint32_t csz
     meta = ok ? (type | (hdr << 2) | fast_copy | fast_lit | (olen << 8)) : 0;
 }
 
+// The same field rules for the per-window batch decoder, which wants the fields themselves (no packing) and is bounded by
+// VALU issue: branch-free selects, 32-bit arithmetic only.  consumed = compressed bytes the element takes; `rejected` = the
+// lanes whose element cannot be valid here (over-long literal, header or literal payload running past the block's compressed
+// size).  Per-lane conditions of this decoder are kept as LANE MASKS built from single compares and combined with scalar
+// logic: a ballot of a compound bool costs a v_cndmask + v_cmp on top of the compares.
+__device__ __forceinline__ void predecode_window(uint64_t w, uint32_t pos, uint32_t csz, uint32_t& type, uint32_t& hdr, uint32_t& olen,
+                                                 uint32_t& off, uint32_t& consumed, unsigned long long& rejected)
+{
+    const uint32_t tag = (uint32_t)w & 0xffu;
+    type = tag & 3u;
+    const uint32_t v = tag >> 2;
+    const uint32_t next4 = (uint32_t)(w >> 8);
+    const bool lit = type == 0;
+    olen = (type == 1) ? (v & 7u) + 4u : v + 1u;                                // :264-266 / :271-273, :278-280, :249
+    hdr = lit ? 1u : ((type == 3) ? 5u : type + 1u);
+    const uint32_t c1_off = ((tag << 3) & 0x700u) | (next4 & 0xffu);
+    off = lit ? 0u : ((type == 1) ? c1_off : ((type == 2) ? (next4 & 0xffffu) : next4));
+    const bool long_lit = lit && v >= 60u;                                       // :250-255, :64-74: v - 59 = 1..4 length bytes
+    const uint32_t raw = next4 & (0xffffffffu >> ((63u - v) * 8u & 31u));       // shift 24, 16, 8, 0 (only read when long_lit)
+    olen = long_lit ? ((raw < 65536u) ? raw + 1u : 0u) : olen;                   // blocks are < 64 KiB
+    hdr = long_lit ? v - 58u : hdr;
+    consumed = hdr + (lit ? olen : 0u);
+    rejected = __ballot(olen == 0) | __ballot(pos + consumed > csz);
+}
+
 // kLdsWindow = true : the decoded block is staged in LDS (block_size bytes, ~4 blocks/CU) and written out at the end;
 //   ~2.7x faster per wavefront (LDS back-references) but only 4 such wavefronts fit per CU.
 // kLdsWindow = false: the decoded block is written straight to its place in global memory and back-references
@@ -1598,6 +1644,36 @@ __device__ __forceinline__ void k2_chain_walk(uint32_t advv, uint32_t wlim, uint
     } while (s < wlim);
 #else
     uint32_t a;
+    // Four elements per trip (a branch that falls through is cheaper than one that is taken).  A full window (wlim == 64, all
+    // but a block's last) needs no compare: with t = s - 64 (mod 2^32) "t += a" carries out exactly when s reaches 64, and
+    // s_bitset1_b64 / v_readlane_b32 only look at the low six bits of their index, which t and s share.
+    if (wlim == 64u) {
+        uint32_t t = s - 64u;
+        asm volatile(
+            "1:\n"
+            "  s_bitset1_b64 %[E], %[t]\n"
+            "  v_readlane_b32 %[a], %[advv], %[t]\n"
+            "  s_add_u32 %[t], %[t], %[a]\n"
+            "  s_cbranch_scc1 2f\n"
+            "  s_bitset1_b64 %[E], %[t]\n"
+            "  v_readlane_b32 %[a], %[advv], %[t]\n"
+            "  s_add_u32 %[t], %[t], %[a]\n"
+            "  s_cbranch_scc1 2f\n"
+            "  s_bitset1_b64 %[E], %[t]\n"
+            "  v_readlane_b32 %[a], %[advv], %[t]\n"
+            "  s_add_u32 %[t], %[t], %[a]\n"
+            "  s_cbranch_scc1 2f\n"
+            "  s_bitset1_b64 %[E], %[t]\n"
+            "  v_readlane_b32 %[a], %[advv], %[t]\n"
+            "  s_add_u32 %[t], %[t], %[a]\n"
+            "  s_cbranch_scc0 1b\n"
+            "2:\n"
+            : [t] "+s"(t), [E] "+s"(E), [a] "=&s"(a)
+            : [advv] "v"(advv)
+            : "scc");
+        s = t + 64u;
+        return;
+    }
     asm volatile(
         "1:\n"
         "  s_bitset1_b64 %[E], %[s]\n"
@@ -1610,6 +1686,10 @@ __device__ __forceinline__ void k2_chain_walk(uint32_t advv, uint32_t wlim, uint
         : "scc");
 #endif
 }
+
+// Output one 64-byte window of compressed data can produce without its last literal's run-on: 22 three-byte copies of 64 bytes
+// (starts 0, 3, .. 63) = 1408; rounded up.
+constexpr uint32_t kK2StageBytes = 1536;
 
 // One K2 launch can serve several streams (their own block offsets, output and status arrays; one block size): the
 // persistent wavefronts draw GLOBAL block numbers and map them to (stream, block), so a batch has one tail instead of one
@@ -1631,6 +1711,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
                                                                                                     uint32_t* next_block)
 {
     HIP_DYNAMIC_SHARED(uint8_t, lds_win)   // kLdsWindow: block_size rounded up to 16; dynamic LDS starts 16-byte aligned
+    __shared__ __attribute__((aligned(16))) uint8_t k2_stage_mem[kBatch ? kK2StageBytes : 16];   // batch form: one window's output
+    lds_bytes_t stage = (lds_bytes_t)k2_stage_mem;
     const uint32_t lane = threadIdx.x;
     const uint32_t num_blocks = w.first_block[w.count];
 
@@ -1674,26 +1756,46 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
         WindowLoad next = {0, 64};  // prefetch of the following 64 bytes (W1), shift applied at use
         WindowLoad next2 = {0, 64}; // batch form: the 64 bytes after those, so that W1 has arrived when a literal runs on into it
         bool have_window = false;
+        // batch form: a window wholly inside the stream (all but the last windows of a stream's last blocks) is a plain load at a
+        // 32-bit offset from the block's first element; the others take window_issue()'s clamped address and tail shift
+        const uint32_t avail32 = avail > 0xffffff00ull ? 0xffffff00u : (uint32_t)avail;
+        bool next_tail = true, next2_tail = true;
+        auto issue = [&](uint32_t base, bool& tail) -> WindowLoad {
+            WindowLoad r;
+            if (base + 72u <= avail32) {
+                r.raw = ld64(src + (base + lane));
+                r.shift = 0;
+                tail = false;
+            } else {
+                r = window_issue(src, (uint64_t)base + lane, avail);
+                tail = true;
+            }
+            return r;
+        };
         while (st == kBlockOk && cp < csz) {                             // one iteration per 64-byte window
-            if (!have_window || cp >= g + 128) {
+            if constexpr (kBatch) {
+                // the batch form rotates its window registers at the END of a window (see there); only the first window of a
+                // block and the one after a long literal load afresh: all three requests go out before the first is awaited
+                if (!have_window) {
+                    g = cp & ~63u;
+                    bool cur_tail;
+                    const WindowLoad cur = issue(g, cur_tail);
+                    next = issue(g + 64u, next_tail);
+                    next2 = issue(g + 128u, next2_tail);
+                    w0 = cur_tail ? window_value(cur) : cur.raw;
+                    have_window = true;
+                }
+            } else if (!have_window || cp >= g + 128) {
                 g = cp & ~63u;
                 const WindowLoad cur = window_issue(src, (uint64_t)g + lane, avail);
-                if constexpr (kBatch) {                                  // all three requests go out before the first is awaited
-                    next = window_issue(src, (uint64_t)g + 64 + lane, avail);
-                    next2 = window_issue(src, (uint64_t)g + 128 + lane, avail);
-                }
                 w0 = window_value(cur);
                 have_window = true;
             } else {                                                     // cp in [g+64, g+128): slide by 64
                 g += 64;
                 w0 = window_value(next);
-                if constexpr (kBatch) {
-                    next = next2;
-                    next2 = window_issue(src, (uint64_t)g + 128 + lane, avail);
-                }
             }
-            uint32_t meta, offv;
-            predecode(w0, g + lane, csz, meta, offv);
+            uint32_t meta = 0, offv = 0;
+            if constexpr (!(kBatch && !kLdsWindow)) predecode(w0, g + lane, csz, meta, offv);
             if constexpr (!kBatch) {
                 // issue the prefetch only after w0 has been consumed, so the wait for w0 cannot cover it
                 __builtin_amdgcn_sched_barrier(0);
@@ -1703,25 +1805,86 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
             if constexpr (kBatch && !kLdsWindow) {
                 // ================= the whole window at once =================
                 const uint32_t wlim = wend - g;
-                const uint32_t e_type = meta & 3u, e_hdr = (meta >> 2) & 7u, e_len = meta >> 8;
-                const uint32_t advv = meta ? e_hdr + (e_type ? 0u : e_len) : 64u;
+                uint32_t e_type, e_hdr, e_len, e_consumed;
+                unsigned long long REJ;
+                predecode_window(w0, g + lane, csz, e_type, e_hdr, e_len, offv, e_consumed, REJ);
+                const uint32_t advv = __builtin_amdgcn_inverse_ballot_w64(REJ) ? 64u : e_consumed;
                 uint32_t s = cp - g;
                 unsigned long long E = 0;
                 k2_chain_walk(advv, wlim, s, E);
-                if (E & __ballot(meta == 0)) {                           // an element predecode rejected
+#ifdef K2X_WALK_TWICE                                                    // sensitivity experiment: the walk's scalar work doubled, same result
+                {
+                    uint32_t s2 = cp - g;
+                    unsigned long long E2 = 0;
+                    uint32_t adv2 = advv;
+                    SNAPPY_PIN(adv2);
+                    k2_chain_walk(adv2, wlim, s2, E2);
+                    E |= E2;
+                    s = s > s2 ? s : s2;
+                }
+#endif
+#ifdef K2X_PREDECODE_TWICE                                               // sensitivity experiment: ~25 more VALU instructions, same result
+                {
+                    uint64_t wx = w0;
+                    SNAPPY_PIN(wx);
+                    uint32_t t2, h2, l2, o2, c2;
+                    unsigned long long R2;
+                    predecode_window(wx, g + lane, csz, t2, h2, l2, o2, c2, R2);
+                    E |= (R2 ^ REJ) | __ballot((t2 ^ e_type) | (h2 ^ e_hdr) | (l2 ^ e_len) | (o2 ^ offv) | (c2 ^ e_consumed));
+                }
+#endif
+                if (E & REJ) {                                           // an element predecode rejected
                     st = kBlockInvalid;
                     break;
                 }
-                const bool is_e = __builtin_amdgcn_inverse_ballot_w64(E);
-                const uint32_t mylen = is_e ? e_len : 0u;
+                const uint32_t mylen = __builtin_amdgcn_inverse_ballot_w64(E) ? e_len : 0u;
                 const uint32_t incl = wave_inclusive_scan(mylen, lane);
                 const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                const uint32_t dstp = op + incl - mylen;                 // where this lane's element writes
-                const bool is_copy = is_e && e_type != 0;
-                if (op + total > out_len || __ballot(is_copy && (offv == 0 || offv > dstp))) {   // strict, cf. :167-173
+                const uint32_t rel = incl - mylen;                       // this lane's element inside the window's output
+                const uint32_t dstp = op + rel;                          // ... and inside the block's
+                const unsigned long long COPY = E & __ballot(e_type != 0);
+                if (op + total > out_len || (COPY & (__ballot(offv == 0) | __ballot(offv > dstp)))) {   // strict, cf. :167-173
                     st = kBlockInvalid;
                     break;
                 }
+                // ================= staged in LDS: the window's output is assembled in k2_stage and flushed once =================
+                // Output bytes [op, op + staged) of this window live in stage[0, staged) until the flush; a back-reference into
+                // them costs an LDS round trip instead of a trip to L2.  Only the part of a last literal that runs on beyond the
+                // 64 window bytes ("spill") bypasses the stage: nothing in this window can refer to it.
+                const uint32_t le = 63u - (uint32_t)__builtin_clzll(E);
+                const uint32_t ps = le + (uint32_t)__builtin_amdgcn_readlane((int)e_hdr, (int)le);
+                const uint32_t pe = ps + (uint32_t)__builtin_amdgcn_readlane((int)e_len, (int)le);
+                const bool spills = (uint32_t)__builtin_amdgcn_readlane((int)e_type, (int)le) == 0 && pe > 64u;
+                const uint32_t staged = total - (spills ? pe - (ps > 64u ? ps : 64u) : 0u);   // a tag in the last lanes: payload from ps > 64
+                if (staged > kK2StageBytes) {                            // cannot happen: 22 copies of 64 bytes are the most 64 bytes can hold
+                    st = kBlockInvalid;
+                    break;
+                }
+                // ---- copies, first part.  "Steppable": does not overlap its own destination and is at least 4 bytes long, so ONE
+                //      lane can do it in unaligned dword steps.  Far ones (source wholly before this window's output) load from
+                //      global memory, all of them together: the loads of their first 8 bytes (most copies of a text end there)
+                //      go out HERE, so that they travel while the literal bytes are placed.  Offsets beyond a copy's length are
+                //      clamped to its last dword: those steps reload and rewrite that dword (same bytes, same place), so the
+                //      loads and stores need no predicate of their own ----
+                const unsigned long long STEP = COPY & __ballot(e_len >= 4u) & __ballot(offv >= e_len);
+                const unsigned long long FAR = STEP & __ballot(offv >= rel + e_len);
+                const unsigned long long NEAR = STEP & __ballot(offv <= rel);
+                const bool is_far = __builtin_amdgcn_inverse_ballot_w64(FAR);
+                const uint32_t last = e_len - 4u;
+                const uint32_t far_o1 = 4u < last ? 4u : last;
+#ifdef K2X_NO_FAR                                                        // timing experiment only (tools/k2x_timing.sh): wrong bytes
+                const uint8_t* sbase = src;
+                const uint32_t so = lane & 3u;
+#else
+                const uint8_t* sbase = win;                              // uniform base + 32-bit lane offset: no 64-bit address arithmetic
+                const uint32_t so = dstp - offv;
+#endif
+                uint32_t far_v0 = 0, far_v1 = 0;
+                if (is_far) {
+                    far_v0 = ld32(sbase + so);
+                    far_v1 = ld32(sbase + (so + far_o1));
+                }
+                __builtin_amdgcn_sched_barrier(0);                       // keep the two loads up here
                 // ---- literals: a payload byte belongs to the last element that starts at or below its lane ----
                 {
                     const uint32_t lo = (uint32_t)E, hi = (uint32_t)(E >> 32);
@@ -1730,78 +1893,81 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
                     const uint32_t blo = lo & mlo, bhi = hi & mhi;
                     const bool any = (blo | bhi) != 0;
                     const uint32_t em = bhi ? 63u - (uint32_t)__builtin_clz(bhi) : (blo ? 31u - (uint32_t)__builtin_clz(blo) : 0u);
-                    const uint32_t packed = (dstp - op) | (e_hdr << 16) | (e_type << 20);     // offsets inside a window are < 4096
+                    const uint32_t packed = rel | (e_hdr << 16) | (e_type << 20);             // offsets inside a window are < 4096
                     const uint32_t pk = (uint32_t)__shfl((int)packed, (int)em);
                     const uint32_t pstart = em + ((pk >> 16) & 7u);
-                    if (any && ((pk >> 20) & 3u) == 0 && lane >= pstart && lane < wlim) win[op + (pk & 0xffffu) + lane - pstart] = (uint8_t)w0;
+                    if (any && ((pk >> 20) & 3u) == 0 && lane >= pstart && lane < wlim) stage[(pk & 0xffffu) + lane - pstart] = (uint8_t)w0;
                 }
-                // a literal that runs on beyond the window is its last element: the next 64 bytes come from the prefetch
-                // registers, anything beyond straight from memory
-                {
-                    const uint32_t le = 63u - (uint32_t)__builtin_clzll(E);
-                    const uint32_t lm = (uint32_t)__builtin_amdgcn_readlane((int)meta, (int)le);
-                    const uint32_t ps = le + ((lm >> 2) & 7u), pe = ps + (lm >> 8);
-                    if ((lm & 3u) == 0 && pe > 64u) {
-                        const uint32_t dbase = (uint32_t)__builtin_amdgcn_readlane((int)dstp, (int)le) - ps;   // byte at g + q goes to dbase + q
-                        WindowLoad nx = next;
-                        SNAPPY_PIN(nx.shift);                            // first use of the prefetch: wait here, not earlier
-                        const uint64_t w1 = window_value(nx);
-                        const uint32_t q = 64u + lane;
-                        if (q >= ps && q < pe) win[dbase + q] = (uint8_t)w1;
-                        if (pe > 128u) {
-                            const uint8_t* __restrict__ p = src + g + 128u;
-                            uint8_t* d = win + (uint32_t)(dbase + 128u);   // dbase may be "negative" (mod 2^32): add before widening
-                            const uint32_t rest = pe - 128u;
-                            uint32_t i = 4 * lane;
-                            for (; i + 4 <= rest; i += 4 * kWave) st32(d + i, ld32(p + i));
-                            for (; i < rest; ++i) d[i] = p[i];
-                        }
+                // the spill: the next 64 bytes come from the prefetch registers, anything beyond straight from memory
+                if (spills) {
+                    const uint32_t dbase = (uint32_t)__builtin_amdgcn_readlane((int)dstp, (int)le) - ps;   // byte at g + q goes to dbase + q
+                    WindowLoad nx = next;
+                    SNAPPY_PIN(nx.shift);                                // first use of the prefetch: wait here, not earlier
+                    const uint64_t w1 = next_tail ? window_value(nx) : nx.raw;
+                    const uint32_t q = 64u + lane;
+                    if (q >= ps && q < pe) win[dbase + q] = (uint8_t)w1;
+                    if (pe > 128u) {
+                        const uint8_t* __restrict__ p = src + g + 128u;
+                        uint8_t* d = win + (uint32_t)(dbase + 128u);     // dbase may be "negative" (mod 2^32): add before widening
+                        const uint32_t rest = pe - 128u;
+                        uint32_t i = 4 * lane;
+                        for (; i + 4 <= rest; i += 4 * kWave) st32(d + i, ld32(p + i));
+                        for (; i < rest; ++i) d[i] = p[i];
                     }
                 }
-                // ---- copies.  A copy that does not overlap its own destination and is at least 4 bytes long can be done by ONE lane
-                //      in unaligned dword steps ("steppable"); every set of steppable copies whose sources lie wholly in finished
-                //      output is done together, four loads per lane in flight before the four stores.  Round 0: sources before
-                //      this window's output (any position in the window).  Later rounds: the first copy still to do, with every
-                //      other one whose source ends before that copy's destination -- all output below it is complete.  The rest
-                //      (overlapping, i.e. :174-181 replicating the last `off` bytes, or shorter than 4) go one at a time ----
+                // ---- copies, second part.  The far copies land in the stage.  Near ones (source wholly inside the stage) go
+                //      LDS -> LDS in rounds: the first copy still to do, with every other near one whose source ends before that
+                //      copy's destination -- all output below it is complete.  The rest (overlapping, i.e. :174-181 replicating
+                //      the last `off` bytes; shorter than 4; source straddling the start of the stage) go one at a time, a lane
+                //      per byte ----
                 {
-                    const bool steppable = is_copy && e_len >= 4u && offv >= e_len;
-                    const uint32_t src_end = dstp - offv + e_len;
-                    const unsigned long long STEP = __ballot(steppable);
-                    const uint8_t* sp = win + (dstp - offv);
-                    uint8_t* dp = win + dstp;
-                    unsigned long long rem = __ballot(is_copy);
-                    unsigned long long ready = rem & __ballot(steppable && src_end <= op);
-                    for (;;) {
-                        if (ready) {
-                            const bool mine = __builtin_amdgcn_inverse_ballot_w64(ready);
-                            // offsets beyond the copy's length are clamped to its last dword: those steps reload and rewrite that
-                            // dword (same bytes, same place), so the four loads and four stores need no predicate of their own
-                            if (mine) {
-                                const uint32_t last = e_len - 4u;
-                                {                                        // bytes 0..7: most copies of a text end here
+                    const uint32_t src_end = rel - offv + e_len;         // meaningful for near copies only
+                    unsigned long long rem = COPY & ~FAR;
+                    lds_bytes_t dp = stage + rel;
+                    if (is_far) {
+                        lds_st32u(dp, far_v0);
+                        lds_st32u(dp + far_o1, far_v1);
+                        for (uint32_t base = 8u; base < e_len; base += 16u) {
+                            const uint32_t o0 = base < last ? base : last, o1 = base + 4u < last ? base + 4u : last,
+                                           o2 = base + 8u < last ? base + 8u : last, o3 = base + 12u < last ? base + 12u : last;
+                            const uint32_t v0 = ld32(sbase + (so + o0)), v1 = ld32(sbase + (so + o1)), v2 = ld32(sbase + (so + o2)),
+                                           v3 = ld32(sbase + (so + o3));
+                            lds_st32u(dp + o0, v0);
+                            lds_st32u(dp + o1, v1);
+                            lds_st32u(dp + o2, v2);
+                            lds_st32u(dp + o3, v3);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#ifdef K2X_NO_NEAR
+                    rem = 0;
+#endif
+                    while (rem) {
+                        const uint32_t f = (uint32_t)__builtin_ctzll(rem);
+                        const uint32_t fd = (uint32_t)__builtin_amdgcn_readlane((int)rel, (int)f);
+                        if ((NEAR >> f) & 1ull) {
+                            const unsigned long long ready = rem & NEAR & __ballot(src_end <= fd);
+                            if (__builtin_amdgcn_inverse_ballot_w64(ready)) {
+                                lds_bytes_t sp = stage + (rel - offv);
+                                {
                                     const uint32_t o1 = 4u < last ? 4u : last;
-                                    const uint32_t v0 = ld32(sp), v1 = ld32(sp + o1);
-                                    st32(dp, v0);
-                                    st32(dp + o1, v1);
+                                    const uint32_t v0 = lds_ld32u(sp), v1 = lds_ld32u(sp + o1);
+                                    lds_st32u(dp, v0);
+                                    lds_st32u(dp + o1, v1);
                                 }
                                 for (uint32_t base = 8u; base < e_len; base += 16u) {
                                     const uint32_t o0 = base < last ? base : last, o1 = base + 4u < last ? base + 4u : last,
                                                    o2 = base + 8u < last ? base + 8u : last, o3 = base + 12u < last ? base + 12u : last;
-                                    const uint32_t v0 = ld32(sp + o0), v1 = ld32(sp + o1), v2 = ld32(sp + o2), v3 = ld32(sp + o3);
-                                    st32(dp + o0, v0);
-                                    st32(dp + o1, v1);
-                                    st32(dp + o2, v2);
-                                    st32(dp + o3, v3);
+                                    const uint32_t v0 = lds_ld32u(sp + o0), v1 = lds_ld32u(sp + o1), v2 = lds_ld32u(sp + o2),
+                                                   v3 = lds_ld32u(sp + o3);
+                                    lds_st32u(dp + o0, v0);
+                                    lds_st32u(dp + o1, v1);
+                                    lds_st32u(dp + o2, v2);
+                                    lds_st32u(dp + o3, v3);
                                 }
                             }
+                            __builtin_amdgcn_wave_barrier();
                             rem &= ~ready;
-                        }
-                        if (!rem) break;
-                        const uint32_t f = (uint32_t)__builtin_ctzll(rem);
-                        const uint32_t fd = (uint32_t)__builtin_amdgcn_readlane((int)dstp, (int)f);
-                        if ((STEP >> f) & 1ull) {
-                            ready = rem & __ballot(steppable && src_end <= fd);
                             continue;
                         }
                         const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)e_len, (int)f);
@@ -1811,14 +1977,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
                             const uint32_t q = (lane * kRecip16[off]) >> 16;
                             src_idx = lane - q * off;
                         }
-                        if (lane < len) win[fd + lane] = win[fd - off + src_idx];
+                        if (lane < len) {
+                            const uint32_t at_stage = fd + src_idx;      // source byte = stage[at_stage - off] when that is inside the stage
+                            const uint8_t v = at_stage >= off ? stage[at_stage - off] : win[op + at_stage - off];
+                            stage[fd + lane] = v;
+                        }
                         __builtin_amdgcn_wave_barrier();
                         rem &= rem - 1;
-                        ready = 0;
                     }
                 }
+                // ---- the next window.  Normally the following 64 bytes: rotate the window registers HERE, before the flush, and
+                //      send the new prefetch into the register that just became free.  (Rotating at the top of the next
+                //      iteration makes the compiler copy a register an outstanding load will write; it then waits at the back
+                //      edge for EVERY outstanding vector memory operation, vmcnt(0), the flush stores included -- a full write
+                //      round trip per window.  Here the two prefetches are a window old, and only stores are in flight at the
+                //      back edge.)  After a literal that ran on beyond the next window the block loads afresh ----
+                const uint32_t flush_at = op;
                 op += total;
                 cp = g + s;
+                if (cp < g + 128u) {
+                    SNAPPY_PIN(next.raw);
+                    SNAPPY_PIN(next2.raw);
+                    w0 = next_tail ? window_value(next) : next.raw;
+                    next = next2;
+                    next_tail = next2_tail;
+                    g += 64;
+                    next2 = issue(g + 128u, next2_tail);
+                } else {
+                    have_window = false;
+                }
+                // ---- flush: stage[0, staged) -> the block's output at op, a dword per lane (the last one clamped back) ----
+#ifndef K2X_NO_FLUSH
+                if (staged >= 4u) {
+                    for (uint32_t i = 4u * lane; i < staged; i += 4u * kWave) {
+                        const uint32_t o = i + 4u <= staged ? i : staged - 4u;
+                        st32(win + flush_at + o, lds_ld32u(stage + o));
+                    }
+                } else if (lane < staged) {
+                    win[flush_at + lane] = stage[lane];
+                }
+#endif
+                __builtin_amdgcn_wave_barrier();
                 continue;
             }
 #ifndef SNAPPY_EMU

@@ -15,6 +15,10 @@ import silesia_mix
 import snappy_hip_binding as shb
 
 
+if os.environ.get("SNAPPY_PROF_LIB"):            # an experimental build of the library (timing experiments)
+    shb.LIB_PATH = os.environ["SNAPPY_PROF_LIB"]
+
+
 def main():
     mib = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     configs = sys.argv[2:] or ["0:0", "1:0", "2:0"]
