@@ -149,3 +149,17 @@ def test_emulated_pair_kernel_under_shuffled_wave_schedules(seed):
     here = os.path.dirname(os.path.abspath(__file__))
     out = subprocess.run([sys.executable, "-c", _PAIR_STRESS, here, str(seed)], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("flavour", [0, 1, 2, 3])
+def test_emulated_decoder_on_random_element_streams(flavour):
+    """Streams no compressor of ours would write (datagen.element_stream): the decoder kernel under the emulator must decode
+    them exactly as the oracle (= the reference's decoder restated) does."""
+    for seed in range(6):
+        bs = (32768, 4097, 700, 65535, 64, 20000)[seed]
+        stream, plain = datagen.element_stream(9000 + 3777 * seed, bs, 1000 * flavour + seed, flavour)
+        st, ref = oracle.decompress(stream)
+        assert st == 0 and ref == plain, (flavour, seed)
+        total, got_bs, hdr = oracle.read_header(stream)
+        st, out = emu.decompress(stream, total, got_bs, hdr)
+        assert st == 0 and out == plain, (flavour, seed, bs)
