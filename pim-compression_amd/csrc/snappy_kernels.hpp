@@ -1350,8 +1350,14 @@ __global__ __launch_bounds__(256) void verify_index_kernel(const StreamDesc* __r
         else
             ++good;
     }
-    if (bad) atomicOr(d.result, kBlockInvalid);
-    if (good) atomicAdd(d.result + 1, good);
+    // one atomic per wavefront, not per thread: 16384 threads per stream adding to one word take 1.4 ms for 20 us of checking
+    const uint32_t wl = threadIdx.x & (kWave - 1);
+    for (uint32_t m = kWave / 2; m; m >>= 1) good += (uint32_t)__shfl((int)good, (int)(wl ^ m));
+    const unsigned long long any_bad = __ballot(bad != 0);
+    if (wl == 0) {
+        if (any_bad) atomicOr(d.result, kBlockInvalid);
+        if (good) atomicAdd(d.result + 1, good);
+    }
 }
 
 // ---------------------------------------------------------------------------
