@@ -1817,7 +1817,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
                 const uint32_t advv = __builtin_amdgcn_inverse_ballot_w64(REJ) ? 64u : e_consumed;
                 uint32_t s = cp - g;
                 unsigned long long E = 0;
+#if defined(SNAPPY_EMU) || defined(K2X_SINGLE_WALK)
                 k2_chain_walk(advv, wlim, s, E);
+#else
+                // The serial walk visits every SECOND element: adv2 = this element's size plus its successor's (one ds_bpermute;
+                // nothing added when the successor starts beyond the window, so the walk still ends on the first start at or
+                // beyond wlim).  The elements in between are filled in afterwards, all at once: every visited lane whose
+                // successor starts inside the window pushes a 1 to it (ds_permute, the forward form); the other lanes push to
+                // lane 0, which cannot be anybody's successor.
+                {
+                    const uint32_t nxt = lane + advv;
+                    const uint32_t a_n = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxt << 2), (int)advv);
+                    const bool has2 = nxt < wlim;
+                    const uint32_t adv2 = advv + (has2 ? a_n : 0u);
+                    k2_chain_walk(adv2, wlim, s, E);
+                    const bool pusher = __builtin_amdgcn_inverse_ballot_w64(E) && has2;
+                    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(pusher ? nxt << 2 : 0u), pusher ? 1 : 0);
+                    E |= __ballot(got != 0) & ~1ull;
+                }
+#endif
 #ifdef K2X_WALK_TWICE                                                    // sensitivity experiment: the walk's scalar work doubled, same result
                 {
                     uint32_t s2 = cp - g;
@@ -1857,10 +1875,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
                 // Output bytes [op, op + staged) of this window live in stage[0, staged) until the flush; a back-reference into
                 // them costs an LDS round trip instead of a trip to L2.  Only the part of a last literal that runs on beyond the
                 // 64 window bytes ("spill") bypasses the stage: nothing in this window can refer to it.
-                const uint32_t le = 63u - (uint32_t)__builtin_clzll(E);
-                const uint32_t ps = le + (uint32_t)__builtin_amdgcn_readlane((int)e_hdr, (int)le);
-                const uint32_t pe = ps + (uint32_t)__builtin_amdgcn_readlane((int)e_len, (int)le);
-                const bool spills = (uint32_t)__builtin_amdgcn_readlane((int)e_type, (int)le) == 0 && pe > 64u;
+                // (the walk ended right behind the window's last element: a literal there ends at pe = s, and only s > 64 can spill)
+                uint32_t le = 0, ps = 0;
+                const uint32_t pe = s;
+                bool spills = false;
+                if (s > 64u) {
+                    le = 63u - (uint32_t)__builtin_clzll(E);
+                    if ((uint32_t)__builtin_amdgcn_readlane((int)e_type, (int)le) == 0) {
+                        ps = le + (uint32_t)__builtin_amdgcn_readlane((int)e_hdr, (int)le);
+                        spills = true;
+                    }
+                }
                 const uint32_t staged = total - (spills ? pe - (ps > 64u ? ps : 64u) : 0u);   // a tag in the last lanes: payload from ps > 64
                 if (staged > kK2StageBytes) {                            // cannot happen: 22 copies of 64 bytes are the most 64 bytes can hold
                     st = kBlockInvalid;
@@ -2015,7 +2040,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
                 // ---- flush: stage[0, staged) -> the block's output at op, a dword per lane (the last one clamped back) ----
 #ifndef K2X_NO_FLUSH
                 if (staged >= 4u) {
-                    for (uint32_t i = 4u * lane; i < staged; i += 4u * kWave) {
+                    {                                                    // the first 256 bytes: all there is in most windows
+                        const uint32_t i = 4u * lane;
+                        const uint32_t o = i + 4u <= staged ? i : staged - 4u;
+                        if (i < staged) st32(win + flush_at + o, lds_ld32u(stage + o));
+                    }
+                    for (uint32_t i = 4u * (lane + kWave); i < staged; i += 4u * kWave) {
                         const uint32_t o = i + 4u <= staged ? i : staged - 4u;
                         st32(win + flush_at + o, lds_ld32u(stage + o));
                     }
