@@ -63,8 +63,31 @@ def run(cases, seed, verbose=True):
     return bad
 
 
+def run_element_streams(cases, seed, verbose=True):
+    """Decoder only: random valid element streams (datagen.element_stream -- what no greedy compressor writes) must decode as
+    the oracle decodes them.  Returns the number of failing cases."""
+    rnd = random.Random(seed)
+    bad = 0
+    for c in range(cases):
+        bs = rnd.choice([rnd.randrange(16, 300), rnd.randrange(300, 5000), rnd.randrange(5000, 65536), 32768, 65535, 4096])
+        n = rnd.randrange(1, 20_000) if bs < 300 else rnd.randrange(1, 300_000)
+        stream, plain = datagen.element_stream(n, bs, rnd.randrange(1 << 30), c % 4)
+        st_ref, ref = oracle.decompress(stream)
+        t = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).cuda()
+        st, d_out = shb.decompress_resident(t, stream_len=len(stream))
+        ok = st_ref == 0 and ref == plain and st == 0 and bytes(d_out.cpu().numpy()) == plain
+        if not ok:
+            print(f"element stream case {c}: n {n} bs {bs} flavour {c % 4} FAILED", flush=True)
+            bad += 1
+        elif verbose and c % 50 == 0:
+            print(f"element stream case {c} ok", flush=True)
+    return bad
+
+
 if __name__ == "__main__":
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    failures = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    failures = run(n_cases, seed)
+    failures += run_element_streams(n_cases // 4, seed + 1)
     print("fuzz done, failures:", failures)
     sys.exit(1 if failures else 0)
