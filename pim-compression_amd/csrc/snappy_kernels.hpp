@@ -1605,16 +1605,20 @@ __device__ __forceinline__ void k2_fast_elements(uint32_t lenv, uint32_t advv, u
 // ---------------------------------------------------------------------------
 // K2, per-window batch (default).  PMC on the element-at-a-time loop showed K2 bound by the scalar unit (3.7e9 SALU
 // instructions per 2 GiB container, 83 % of what the chip's scalar units can issue in the kernel's time, against 2.4e9 VALU).
-// Here the only per-element scalar work left is following the element chain (v_readlane + add + compare + branch); everything
-// else is done for all elements of a 64-byte window at once:
+// Here the only per-element scalar work left is following the element chain, and that over PAIRS of elements (k2_chain_walk
+// on a doubled jump vector, the skipped starts filled in with one ds_permute); everything else is done for all elements of a
+// 64-byte window at once, and the window's OUTPUT -- at most 1408 bytes -- is assembled in a per-wavefront LDS stage and
+// flushed to the block's place in global memory once:
 //   * output offsets: exclusive prefix sum of the elements' lengths (DPP row scans), one bounds check for the window;
 //   * literals: every payload byte of the window finds its element (the last element start at or below its lane) and its
-//     output position with one ds_bpermute, ONE byte store for all literals of the window;
-//   * copies whose source lies wholly before this window's output and does not overlap their destination (the common case
-//     in text): one LANE per copy, unaligned dword load / store steps, all such copies of the window in parallel;
-//   * the other copies (source inside this window's output, or overlapping, or shorter than 4): in element order, one
-//     predicated byte load + store each, as before -- loads issued after the stores above see them (same-wavefront
-//     global_* operations complete in order; tests/test_abi_symbols.py keeps flat_* out of this kernel).
+//     place in the stage with one ds_bpermute, ONE byte write for all literals of the window;
+//   * "far" copies (source wholly before this window's output, no overlap with their destination, >= 4 bytes): one LANE per
+//     copy, unaligned dword steps global -> stage, all of them together;
+//   * "near" copies (source wholly inside the stage): the same steps LDS -> LDS, in dependency rounds;
+//   * the other copies (overlapping, shorter than 4, straddling the start of the stage): in element order, a lane per byte;
+//   * flush: a dword per lane, stage -> global.  Loads of later windows see it: same-wavefront global_* operations complete
+//     in order (tests/test_abi_symbols.py keeps flat_* out of this kernel).
+// DESIGN.md 3.2 has the measurements behind each choice.
 // Same strictness as the element loop: any invalid element, overrun of the block's output, zero offset or reach before
 // the block start makes the block invalid.
 // ---------------------------------------------------------------------------
