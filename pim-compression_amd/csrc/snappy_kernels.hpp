@@ -1821,7 +1821,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
                 const uint32_t advv = __builtin_amdgcn_inverse_ballot_w64(REJ) ? 64u : e_consumed;
                 uint32_t s = cp - g;
                 unsigned long long E = 0;
-#if defined(SNAPPY_EMU) || defined(K2X_SINGLE_WALK)
+#ifdef K2X_SINGLE_WALK
                 k2_chain_walk(advv, wlim, s, E);
 #else
                 // The serial walk visits every SECOND element: adv2 = this element's size plus its successor's (one ds_bpermute;

@@ -66,9 +66,14 @@ static void complete(WaveSlot& w)
             if (first < 0) first = l;
             if (w.op == OP_BALLOT && w.val[l]) ballot |= 1ull << l;
         }
+    uint64_t pushed[64] = {0};
+    if (w.op == OP_PERMUTE)
+        for (int l = 0; l < 64; ++l)
+            if (w.arg[l] != 0xdeadbeefu) pushed[w.arg[l] & 63] = w.val[l];
     for (int l = 0; l < 64; ++l) {
         if (w.arg[l] == 0xdeadbeefu) continue;
         switch (w.op) {
+        case OP_PERMUTE: r[l] = pushed[l]; break;
         case OP_FIRSTLANE: r[l] = w.val[first]; break;
         case OP_BALLOT: r[l] = ballot; break;
         case OP_READLANE: r[l] = w.val[w.arg[l] & 63]; break;

@@ -34,7 +34,7 @@ const Dim& gdim();
 const Dim& bdim();
 void* dynamic_lds();
 
-enum Op { OP_FIRSTLANE = 1, OP_BALLOT, OP_READLANE, OP_SHFL_UP, OP_BARRIER };
+enum Op { OP_FIRSTLANE = 1, OP_BALLOT, OP_READLANE, OP_SHFL_UP, OP_BARRIER, OP_PERMUTE };
 uint64_t collective(Op op, uint64_t value, uint32_t arg, int site);
 void syncthreads(int site);
 }  // namespace emu
@@ -49,6 +49,10 @@ void syncthreads(int site);
 #define __builtin_amdgcn_wave_barrier() ((void)emu::collective(emu::OP_BARRIER, 0, 0, __LINE__))
 #define __ballot(p) ((unsigned long long)emu::collective(emu::OP_BALLOT, (uint64_t)((p) ? 1 : 0), 0, __LINE__))
 #define __shfl(v, l) ((int)emu::collective(emu::OP_READLANE, (uint64_t)(uint32_t)(v), (uint32_t)(l), __LINE__))
+// ds_bpermute_b32 (pull: lane l reads the value of lane addr[l] / 4) and ds_permute_b32 (push: lane l sends its value to
+// lane addr[l] / 4; the highest sender wins, lanes nobody sends to read 0); both take the lane number from address bits 7:2
+#define __builtin_amdgcn_ds_bpermute(a, v) ((int)emu::collective(emu::OP_READLANE, (uint64_t)(uint32_t)(v), ((uint32_t)(a) >> 2) & 63u, __LINE__))
+#define __builtin_amdgcn_ds_permute(a, v) ((int)emu::collective(emu::OP_PERMUTE, (uint64_t)(uint32_t)(v), ((uint32_t)(a) >> 2) & 63u, __LINE__))
 #define __shfl_up(v, d) ((int)emu::collective(emu::OP_SHFL_UP, (uint64_t)(uint32_t)(v), (uint32_t)(d), __LINE__))
 #define __syncthreads() emu::syncthreads(__LINE__)
 #define SNAPPY_EMU 1
