@@ -1922,14 +1922,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
                 __builtin_amdgcn_sched_barrier(0);                       // keep the two loads up here
                 // ---- literals: a payload byte belongs to the last element that starts at or below its lane ----
                 {
-                    const uint32_t lo = (uint32_t)E, hi = (uint32_t)(E >> 32);
-                    const uint32_t mlo = lane >= 31u ? 0xffffffffu : ((2u << lane) - 1u);
-                    const uint32_t mhi = lane < 32u ? 0u : (lane == 63u ? 0xffffffffu : ((2u << (lane - 32u)) - 1u));
-                    const uint32_t blo = lo & mlo, bhi = hi & mhi;
-                    const bool any = (blo | bhi) != 0;
-                    const uint32_t em = bhi ? 63u - (uint32_t)__builtin_clz(bhi) : (blo ? 31u - (uint32_t)__builtin_clz(blo) : 0u);
+                    const unsigned long long below = E & (~0ull >> (63u - lane));         // element starts at or below this lane
+                    const bool any = below != 0;
+                    const uint32_t em = 63u - (uint32_t)__builtin_clzll(below | 1ull);     // branch-free: 0 when there is none
                     const uint32_t packed = rel | (e_hdr << 16) | (e_type << 20);             // offsets inside a window are < 4096
-                    const uint32_t pk = (uint32_t)__shfl((int)packed, (int)em);
+                    const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(em << 2), (int)packed);
                     const uint32_t pstart = em + ((pk >> 16) & 7u);
                     if (any && ((pk >> 20) & 3u) == 0 && lane >= pstart && lane < wlim) stage[(pk & 0xffffu) + lane - pstart] = (uint8_t)w0;
                 }
