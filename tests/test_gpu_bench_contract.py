@@ -1,0 +1,54 @@
+"""GPU test: bench.py's one JSON line keeps the driver's contract (small run: 2 containers of 64 MiB), and the multi-rank path
+runs with two ranks on this one device (gloo for the control plane, as the CPU tests do)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # exactly ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_json_line_keeps_the_contract():
+    d = _run([sys.executable, "bench.py", "--containers", "2", "--container-mib", "64", "--steps", "2", "--warmup", "1"])
+    assert REQUIRED <= set(d), REQUIRED - set(d)
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        assert d["metric"] == json.load(f)["metric"]
+    assert d["unit"] == "GB/s" and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["scaling"] == "strong" and d["vs_baseline"] is None and d["dtype"] == "u8" and "synthetic" in d["data"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = bytes of all containers / step time
+    assert abs(d["value"] - 2 * 64 * 2**20 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.02 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 and 0 < r["frac"] < 1
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "GB/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert c["gpu_stream_equals_oracle_stream"] is True
+
+
+def test_bench_two_ranks_on_one_device():
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", "29531", "bench.py", "--gpus", "2", "--containers", "2", "--container-mib", "64", "--steps", "2",
+              "--warmup", "1", "--no-cpu-baseline"],
+             env={"SNAPPY_BENCH_BACKEND": "gloo", "SNAPPY_BENCH_SINGLE_DEVICE": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["containers_this_rank"] == 1               # the two containers were dealt one per rank
