@@ -494,6 +494,9 @@ def main():
                          "traffic": traffic, "lds_table_block_share": round(share, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(c_ms, 4),
                          "decompress_kernel": {"achieved": round(d_algo / (d_ms * 1e-3) / 1e9, 3),
+                                               "frac": round(d_algo / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
+                                               "traffic": int(u * pmc["k2_bytes_per_output_byte"])
+                                               if pmc and "k2_bytes_per_output_byte" in pmc else None,
                                                "algorithmic_bytes_per_launch": int(d_algo),
                                                "avg_launch_ms": round(d_ms, 4)}},
         }
