@@ -534,7 +534,10 @@ struct MaskedWindowState {
         const bool g = __builtin_amdgcn_inverse_ballot_w64(gm);
         const uint32_t mine_l = win.e0 | (win.base + lane);
         if (g) ent = table.load_lane(win.h0, mine_l);
-        if (kWithDup && !dup_valid) {                  // run the LDS duplicate test underneath the table loads
+        // The LDS duplicate test (three dependent LDS round trips) runs underneath the longest loads of the gather: the table
+        // loads when the table is in global memory, the candidate loads when it is in LDS (its entries arrive at once).
+        constexpr bool kDupUnderCandidates = std::is_same<Table, LdsTable>::value;
+        if (kWithDup && !dup_valid && !kDupUnderCandidates) {
             __builtin_amdgcn_sched_barrier(0);
             dup = dup_slot_lanes(scratch, win.h0, lane);
             dup_valid = true;
@@ -560,6 +563,12 @@ struct MaskedWindowState {
                 o5 = ld32(o + 20);
                 o6 = ld32(o + 24);
             }
+        }
+        if (kWithDup && !dup_valid && kDupUnderCandidates) {
+            __builtin_amdgcn_sched_barrier(0);
+            dup = dup_slot_lanes(scratch, win.h0, lane);
+            dup_valid = true;
+            __builtin_amdgcn_sched_barrier(0);
         }
         xa = bytes_ahead(win, lane, 4);
         xb = bytes_ahead(win, lane, 8);
