@@ -129,7 +129,7 @@ def main():
     host = host.replace('"../../include/snappy_hip.h"', '"%s"' % os.path.join(ROOT, "include", "snappy_hip.h"))
     open(os.path.join(tmp, "snappy_hip.hip"), "w").write(host)
     out = os.path.join(ROOT, "pim-compression_amd", "libsnappy_hip_prof.so")
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC,   # the other headers
                            os.path.join(tmp, "snappy_hip.hip"), "-o", out])
     shutil.rmtree(tmp)
     print(out)
