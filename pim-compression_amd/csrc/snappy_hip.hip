@@ -111,6 +111,7 @@ constexpr int kDefaultK1FormLds = 2;    // bulk form for the LDS-table kernel
 constexpr int kDefaultLdsWaves = 768;   // block sizes above 8 KiB: 3 LDS-table wavefronts per CU (3 x 33 KiB) beside 20 global-table ones (3 KiB each: filter + duplicate test)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 constexpr uint32_t kCus = 256, kLdsPerCu = 160u << 10, kWaveSlotsPerCu = 32;
+constexpr int kDefaultK1Stream = 0;     // SNAPPY_HIP_K1_STREAM: bit 0 = stream form (snappy_k1_stream.hpp) for the LDS-table kernel, bit 1 = for the global-table kernel
 constexpr int kDefaultPairPerCu = 0;    // two-wavefront LDS-table workgroups per CU beside the global-table wavefronts (0 = round 1's one-wavefront LDS-table kernel)
 
 // Work counters for persistent kernels: a ring in the code object's own global memory (one copy per device), so launches
@@ -398,8 +399,12 @@ void launch_lds_table_kernel(const K1Forms& f, uint32_t grid, hipStream_t st, co
 #ifdef SNAPPY_ABLATION
     SNAPPY_K1_DISPATCH(launch_k1_lds, f.ahead_lds, f.form_lds, grid, f.extra_lds, st, w, block_size, slot_stride, counter);
 #else
-    hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<64, 2>), dim3(grid), dim3(64),
-                       snappy_hip::lds_table_kernel_lds_bytes(block_size, true), st, w, block_size, slot_stride, counter);
+    if (env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream))
+        hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<64, 3>), dim3(grid), dim3(64),
+                           snappy_hip::lds_table_stream_lds_bytes(block_size), st, w, block_size, slot_stride, counter);
+    else
+        hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<64, 2>), dim3(grid), dim3(64),
+                           snappy_hip::lds_table_kernel_lds_bytes(block_size, true), st, w, block_size, slot_stride, counter);
     (void)f;
 #endif
 }
@@ -415,8 +420,18 @@ void launch_global_table_kernel(const K1Forms& f, uint32_t grid, hipStream_t st,
     else
         SNAPPY_K1_DISPATCH(launch_k1_global, f.ahead, f.form, grid, st, w, block_size, slot_stride, tables, counter);
 #else
-    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 2, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
-                       slot_stride, tables, counter);
+    if (env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream) & 2)
+        hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 3, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
+                           slot_stride, tables, counter);
+    else if (env_int("SNAPPY_HIP_GT_CHUNK", 64) == 32)
+        hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<32, 2, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
+                           slot_stride, tables, counter);
+    else if (env_int("SNAPPY_HIP_GT_CHUNK", 64) == 16)
+        hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<16, 2, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
+                           slot_stride, tables, counter);
+    else
+        hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 2, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
+                           slot_stride, tables, counter);
     (void)f;
 #endif
 }
@@ -494,6 +509,18 @@ uint32_t snappy_hip_parse_header(const uint8_t* src, uint64_t avail, uint32_t* t
     if (!b) return 0;
     return a + b;
 }
+
+#ifdef SNAPPY_PROF
+// probe builds only (tools/prof_stream.py): read / reset the lap timers of the stream form
+int snappy_hip_debug_prof(unsigned long long* out, int reset)
+{
+    if (reset) {
+        unsigned long long z[32] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(snappy_hip::g_prof), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(snappy_hip::g_prof), 32 * sizeof(unsigned long long));
+}
+#endif
 
 uint32_t snappy_hip_k1_lds_waves_per_cu(uint32_t block_size)
 {
@@ -585,7 +612,9 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
     uint32_t* counter = static_cast<uint32_t*>(d_scratch);
     uint32_t* tables = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_scratch) + 256);
     HIP_TRY(hipMemsetAsync(counter, 0, 32, st));   // [0] next block, [4] blocks compressed by wavefronts with an LDS table
-    const uint32_t g_wave_bytes = ((forms.form ? 1u : 0u) + (forms.filter == 2 ? 4u : (forms.filter ? 2u : 0u))) << 10;
+    const int k1_stream = env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream);
+    const uint32_t g_wave_bytes = (k1_stream & 2) ? (2u << 10) + snappy_hip::stream_scratch_bytes(snappy_hip::kStreamSlotsGlobal)
+                                                  : ((forms.form ? 1u : 0u) + (forms.filter == 2 ? 4u : (forms.filter ? 2u : 0u))) << 10;
     // fork / join around the caller's stream: `lds_launch` goes to the helper stream, the global-table kernel stays on `st`
     auto co_run = [&](uint32_t g, const std::function<void(hipStream_t)>& lds_launch) -> int {
         CoRunResources* cr = nullptr;
@@ -635,7 +664,8 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
     uint32_t waves;
     {
         const uint32_t lds_per_cu = (lds_waves + kCus - 1) / kCus;
-        const uint32_t lds_wave_bytes = snappy_hip::lds_table_kernel_lds_bytes(block_size, forms.form_lds != 0) + forms.extra_lds;
+        const uint32_t lds_wave_bytes = ((k1_stream & 1) ? snappy_hip::lds_table_stream_lds_bytes(block_size)
+                                                         : snappy_hip::lds_table_kernel_lds_bytes(block_size, forms.form_lds != 0)) + forms.extra_lds;
         uint32_t g_per_cu = kWaveSlotsPerCu > lds_per_cu ? kWaveSlotsPerCu - lds_per_cu : 0u;
         if (g_wave_bytes && lds_per_cu * lds_wave_bytes < kLdsPerCu)
             g_per_cu = std::min(g_per_cu, (kLdsPerCu - lds_per_cu * lds_wave_bytes) / g_wave_bytes);

@@ -622,6 +622,57 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m, uint32_t add)
 // lanes [0, n), 1 <= n <= 64
 __device__ __forceinline__ unsigned long long lanes_below(uint32_t n) { return ~0ull >> (64u - n); }
 
+// Emission of one segment (:355, :202-245) by the lanes themselves.  H = lanes whose probe hit (their copy: candidate in
+// `ent`, length 4 + extv), COV = lanes covered by those copies, r = where the cursor stands afterwards relative to `base`
+// (by_copy: right behind the last copy, possibly beyond the window; otherwise the literal after the last copy stays
+// pending).  Each lane derives its own output offset from the masks with v_mbcnt:
+//     P(l) = op + #literal bytes + 2 * #copies + #3-byte copies + #literal headers   (all counted below lane l)
+// literal lanes store their byte (byte 0 of x0 IS block byte base + l), run-start lanes the literal header, hit lanes the
+// 2- or 3-byte copy element.
+__device__ __forceinline__ void emit_segment(uint8_t* __restrict__ dst, const uint8_t* __restrict__ blk, uint32_t& op, uint32_t& next_emit,
+                                             uint32_t base, uint32_t x0, uint32_t ent, uint32_t extv, unsigned long long H,
+                                             unsigned long long COV, bool by_copy, uint32_t r, uint32_t lane)
+{
+    const uint32_t r_end = r < kWave ? r : kWave;
+    const uint32_t first_hit = (uint32_t)__builtin_ctzll(H);
+    const uint32_t last_end = by_copy ? r_end : 64u - (uint32_t)__builtin_clzll(COV);
+    uint32_t s0 = first_hit;
+    const uint32_t p0 = base + first_hit;
+    if (next_emit >= base && p0 - next_emit <= 60u) {
+        s0 = next_emit - base;                       // the first run is inside the window too
+    } else if (p0 > next_emit) {                     // it started in an earlier window (or is 61+ bytes)
+        op = emit_literal_windowed(dst, op, blk, next_emit, p0 - next_emit, base, x0, lane);
+    }
+    const unsigned long long LIT = ((~0ull << s0) & lanes_below(last_end)) & ~COV;
+    const unsigned long long LS = LIT & ~(LIT << 1);            // first lane of each literal run
+    const uint32_t off = base + lane - (ent & 0xffffu);         // meaningful in H lanes
+    const uint32_t len = 4u + extv;
+    const bool is_hit = __builtin_amdgcn_inverse_ballot_w64(H);
+    const bool three = off >= 2048u || len >= 12u;                 // :234-245
+    const unsigned long long H3 = __ballot(is_hit && three);
+    uint32_t P = mbcnt64(H, 0);
+    P = mbcnt64(LIT, op + 2u * P);
+    P = mbcnt64(H3, P);
+    P = mbcnt64(LS, P);
+    const bool is_ls = __builtin_amdgcn_inverse_ballot_w64(LS);
+    if (__builtin_amdgcn_inverse_ballot_w64(LIT)) dst[P + (is_ls ? 1u : 0u)] = (uint8_t)x0;
+    if (is_ls) {
+        const uint32_t runlen = (uint32_t)__builtin_ctzll(~LIT >> lane);   // a copy follows every run
+        dst[P] = (uint8_t)((runlen - 1) << 2);                          // :202-207, runs here are <= 60
+    }
+    if (is_hit) {
+        uint32_t b0;
+        if (!three) b0 = 1u + ((len - 4u) << 2) + ((off >> 8) << 5);        // :234-239
+        else b0 = 2u + ((len - 1u) << 2);                                   // :240-245
+        dst[P] = (uint8_t)b0;
+        dst[P + 1] = (uint8_t)off;
+        if (three) dst[P + 2] = (uint8_t)(off >> 8);
+    }
+    op += (uint32_t)__builtin_popcountll(LIT) + 2u * (uint32_t)__builtin_popcountll(H) + (uint32_t)__builtin_popcountll(H3) +
+          (uint32_t)__builtin_popcountll(LS);
+    next_emit = base + (by_copy ? r : last_end);
+}
+
 // The walk of one segment.  `inter` = HIT | stop lanes (stop = DUP, long matches, and every lane >= hi), `lenv` = per-lane
 // match length for HIT lanes (4..63), r < hi <= 64 the cursor lane, B the number of stride-1 probes still allowed (:339).
 // Per match: skip the misses (first set bit of inter), take the hit (H), cover its lanes (COV), continue behind it.
@@ -691,41 +742,46 @@ __device__ __forceinline__ uint32_t segment_walk(unsigned long long inter, unsig
     return why;
 }
 
-template <class Table, uint32_t kChunk>
-__device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restrict__ base16, uint64_t start, uint64_t in_len,
-                                                        uint32_t n, uint8_t* __restrict__ dst, const Table table_in, uint32_t lane,
-                                                        uint32_t* __restrict__ block_bytes_out, lds_bytes_t dup_scratch)
-{
-    using State = MaskedWindowState<Table, kChunk>;
-    const uint8_t* __restrict__ blk = base16 + start;
-    const uint32_t ts = table_entries_for(n);                    // get_hash_table, :139-146 (+ shift, :288)
-    const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
-    // "empty" = candidate position 0 (:346 on a zeroed table), carrying position 0's tag
-    const uint32_t e_zero = (n >= kInputMargin) ? (((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u) : 0u;
-    const Table table = table_in.with_empty(e_zero);
-    if (n >= kInputMargin) table.init(ts, e_zero, lane);
-    __builtin_amdgcn_wave_barrier();
-
+// The scan state of one block between two steps of the parse (snappy_compress.c:284-413): the cursor, the reference's skip
+// counter (:333, :339; 31 marks "the next probe is the one right after a copy", :393-398, which moves on by one position
+// like a stride-1 scan probe and leaves skip = 32 behind), the output offset in the slot and the start of the pending literal.
+struct ParseState {
+    uint32_t ip = 1;          // :305
+    uint32_t skip = 32;       // :333
     uint32_t op = 4;          // :291
     uint32_t next_emit = 0;   // :298
+};
 
-    if (n >= kInputMargin) {  // :301
+// The bulk parse from `ps` on: steps until the scan is over (returns true: the caller emits the remainder, :405-410) or --
+// after at least one step -- the cursor has reached stop_ip at stride 1 (returns false; the table, the slot and `ps` are
+// exactly the reference's state in front of the probe at ps.ip, so any form of the parse can take over).
+template <class Table, uint32_t kChunk>
+__device__ __forceinline__ bool bulk_run(const uint8_t* __restrict__ blk, uint32_t avail, uint32_t n, uint32_t shift,
+                                         uint8_t* __restrict__ dst, const Table table, uint32_t lane, lds_bytes_t dup_scratch,
+                                         ParseState& ps, uint32_t stop_ip)
+{
+    using State = MaskedWindowState<Table, kChunk>;
+    uint32_t op = ps.op;
+    uint32_t next_emit = ps.next_emit;
+    bool finished = true;
+    {
         const uint32_t limit = n - kInputMargin;
-        const uint64_t left = in_len - start;
         CursorWindow win;
         win.blk = blk;
-        win.avail = (left < 0x7fffffffull) ? (uint32_t)left : 0x7fffffffu;
+        win.avail = avail;
         win.shift = shift;
-        win.reset(0, lane);
+        win.reset(ps.ip, lane);
         State st;
-        uint32_t ip = 1;      // :305
-        // `skip` is the reference's counter (:333, :339) for scan probes; 31 marks "the next probe is the one right after
-        // a copy" (:393-398), which moves on by one position like a stride-1 scan probe and leaves skip = 32 behind.
-        uint32_t skip = 32;
-        for (;;) {
+        uint32_t ip = ps.ip;
+        uint32_t skip = ps.skip;
+        for (uint32_t iter = 0;; ++iter) {
             const uint32_t stride = skip >> 5;
             const uint32_t step = stride ? stride : 1u;
             if (ip + step > limit) break;                        // :342-343 / :388-389
+            if (iter && ip >= stop_ip && skip < 64u) {
+                finished = false;
+                break;
+            }
             if (win.ensure(ip, lane)) st.invalidate();
             uint32_t r = ip - win.base;
             if (r >= uni(st.cov_end)) st.template gather<true, true>(table, win, dup_scratch, r, kChunk, lane, n);
@@ -851,54 +907,7 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
                 for (unsigned long long d = C & st.dup; d; d &= d - 1)                         // shared slots: in position order
                     State::commit(table, win, d & (~d + 1), lane);
 
-#ifdef K1X_NO_EMIT        // timing experiment of tools/k1x_pmc.sh (wrong bytes on purpose; never defined in a product build)
-                if (H) {
-                    op += 8;
-                    next_emit = win.base + ((why == 0) ? r : 64u - (uint32_t)__builtin_clzll(COV));
-                }
-                if (false) {
-#else
-                if (H) {
-#endif
-                    // ---- emission ----
-                    const uint32_t first_hit = (uint32_t)__builtin_ctzll(H);
-                    const uint32_t last_end = (why == 0) ? r_end : 64u - (uint32_t)__builtin_clzll(COV);
-                    uint32_t s0 = first_hit;
-                    const uint32_t p0 = win.base + first_hit;
-                    if (next_emit >= win.base && p0 - next_emit <= 60u) {
-                        s0 = next_emit - win.base;               // the first run is inside the window too
-                    } else if (p0 > next_emit) {                 // it started in an earlier window (or is 61+ bytes)
-                        op = emit_literal_windowed(dst, op, blk, next_emit, p0 - next_emit, win.base, win.x0, lane);
-                    }
-                    const unsigned long long LIT = ((~0ull << s0) & lanes_below(last_end)) & ~COV;
-                    const unsigned long long LS = LIT & ~(LIT << 1);            // first lane of each literal run
-                    const uint32_t off = win.base + lane - (st.ent & 0xffffu);  // meaningful in H lanes
-                    const uint32_t len = 4u + st.extv;
-                    const bool is_hit = __builtin_amdgcn_inverse_ballot_w64(H);
-                    const bool three = off >= 2048u || len >= 12u;                 // :234-245
-                    const unsigned long long H3 = __ballot(is_hit && three);
-                    uint32_t P = mbcnt64(H, 0);
-                    P = mbcnt64(LIT, op + 2u * P);
-                    P = mbcnt64(H3, P);
-                    P = mbcnt64(LS, P);
-                    const bool is_ls = __builtin_amdgcn_inverse_ballot_w64(LS);
-                    if (__builtin_amdgcn_inverse_ballot_w64(LIT)) dst[P + (is_ls ? 1u : 0u)] = (uint8_t)win.x0;
-                    if (is_ls) {
-                        const uint32_t runlen = (uint32_t)__builtin_ctzll(~LIT >> lane);   // a copy follows every run
-                        dst[P] = (uint8_t)((runlen - 1) << 2);                          // :202-207, runs here are <= 60
-                    }
-                    if (is_hit) {
-                        uint32_t b0;
-                        if (!three) b0 = 1u + ((len - 4u) << 2) + ((off >> 8) << 5);        // :234-239
-                        else b0 = 2u + ((len - 1u) << 2);                                   // :240-245
-                        dst[P] = (uint8_t)b0;
-                        dst[P + 1] = (uint8_t)off;
-                        if (three) dst[P + 2] = (uint8_t)(off >> 8);
-                    }
-                    op += (uint32_t)__builtin_popcountll(LIT) + 2u * (uint32_t)__builtin_popcountll(H) +
-                          (uint32_t)__builtin_popcountll(H3) + (uint32_t)__builtin_popcountll(LS);
-                    next_emit = win.base + ((why == 0) ? r : last_end);
-                }
+                if (H) emit_segment(dst, blk, op, next_emit, win.base, win.x0, st.ent, st.extv, H, COV, why == 0, r, lane);
                 if (done) break;
                 if (why == 0 && r > kWave) {                     // :391-392 for a copy that ended in a later window
                     if (win.ensure(ip - 1, lane)) st.invalidate();
@@ -959,16 +968,55 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
             st.inserted |= 1ull << (ip - 1 - win.base);
             skip = 31;
         }
+        ps.ip = ip;
+        ps.skip = skip;
     }
+    ps.op = op;
+    ps.next_emit = next_emit;
+    return finished;
+}
 
-    // emit_remainder (:405-410) and the size prefix (:412)
-    if (next_emit < n) op = emit_literal(dst, op, blk + next_emit, n - next_emit, lane);
+// emit_remainder (:405-410) and the size prefix (:412)
+__device__ __forceinline__ void finish_block(const uint8_t* __restrict__ blk, uint32_t n, uint8_t* __restrict__ dst, const ParseState& ps,
+                                             uint32_t lane, uint32_t* __restrict__ block_bytes_out)
+{
+    uint32_t op = ps.op;
+    if (ps.next_emit < n) op = emit_literal(dst, op, blk + ps.next_emit, n - ps.next_emit, lane);
     if (lane == 0) {
         st32(dst, op - 4);
         *block_bytes_out = op;
     }
     __builtin_amdgcn_wave_barrier();
 }
+
+template <class Table, uint32_t kChunk>
+__device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restrict__ base16, uint64_t start, uint64_t in_len,
+                                                        uint32_t n, uint8_t* __restrict__ dst, const Table table_in, uint32_t lane,
+                                                        uint32_t* __restrict__ block_bytes_out, lds_bytes_t dup_scratch)
+{
+    const uint8_t* __restrict__ blk = base16 + start;
+    const uint32_t ts = table_entries_for(n);                    // get_hash_table, :139-146 (+ shift, :288)
+    const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
+    // "empty" = candidate position 0 (:346 on a zeroed table), carrying position 0's tag
+    const uint32_t e_zero = (n >= kInputMargin) ? (((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u) : 0u;
+    const Table table = table_in.with_empty(e_zero);
+    if (n >= kInputMargin) table.init(ts, e_zero, lane);
+    __builtin_amdgcn_wave_barrier();
+    ParseState ps;
+    if (n >= kInputMargin) {  // :301
+        const uint64_t left = in_len - start;
+        const uint32_t avail = (left < 0x7fffffffull) ? (uint32_t)left : 0x7fffffffu;
+        bulk_run<Table, kChunk>(blk, avail, n, shift, dst, table, lane, dup_scratch, ps, 0xffffffffu);
+    }
+    finish_block(blk, n, dst, ps, lane, block_bytes_out);
+}
+
+}  // namespace snappy_hip
+#include "snappy_k1_stream.hpp"
+namespace snappy_hip {
+
+// dynamic LDS of the LDS-table kernel in its stream form: the u16 table + the two tables of analyse()
+__host__ __device__ inline uint32_t lds_table_stream_lds_bytes(uint32_t block_size);
 
 // ~3.4 us per iteration (s_sleep 127 = 127 x 64 cycles).  The hybrid K1 launch puts a few of these in front of the
 // global-table kernel so that the LDS-table workgroups of the co-running kernel (33 KiB of LDS each) are placed first:
@@ -1012,6 +1060,10 @@ __host__ __device__ inline uint32_t lds_table_entries(uint32_t block_size)
 __host__ __device__ inline uint32_t lds_table_kernel_lds_bytes(uint32_t block_size, bool with_dup_scratch)
 {
     return 2u * lds_table_entries(block_size) + (with_dup_scratch ? kDupSlots : 16u);
+}
+__host__ __device__ inline uint32_t lds_table_stream_lds_bytes(uint32_t block_size)
+{
+    return 2u * lds_table_entries(block_size) + stream_scratch_bytes(kStreamSlotsLds);
 }
 
 // next_block == nullptr: static grid-stride assignment; otherwise blocks are drawn from the shared atomic counter,
@@ -1060,8 +1112,12 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const K1B
             compress_one_block_windowed<LdsTable, kAhead>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out);
         else
 #else
-        static_assert(kForm == 2, "the product ships the bulk form; other forms need -DSNAPPY_ABLATION");
+        static_assert(kForm == 2 || kForm == 3, "the product ships the bulk and stream forms; other forms need -DSNAPPY_ABLATION");
 #endif
+        if constexpr (kForm == 3)   // (launched with lds_table_stream_lds_bytes(block_size) of dynamic LDS)
+            compress_one_block_stream<LdsTable, kStreamSlotsLds>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out,
+                                                                 (lds_bytes_t)dup_scratch);
+        else
             compress_one_block_bulk<LdsTable, kAhead>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out,
                                                       (lds_bytes_t)dup_scratch);
         if (next_block && lane == 0) atomicAdd(next_block + 4, 1u);   // statistics: blocks taken by the LDS-table form
@@ -1075,14 +1131,14 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
                                                                           uint32_t* table_scratch, uint32_t* next_block)
 {
     const uint32_t num_blocks = w.first_block[w.count];
-    __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kForm ? kDupSlots : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kForm == 3 ? stream_scratch_bytes(kStreamSlotsGlobal) : (kForm ? kDupSlots : 16)];
     __shared__ __attribute__((aligned(16))) uint32_t slot_state[kFilter == 2 ? kMaxTableEntries / 16 : (kFilter ? kMaxTableEntries / 32 : 4)];
     const uint32_t lane = threadIdx.x;
 #ifdef SNAPPY_ABLATION
     using Table = typename std::conditional<kFilter == 2, ClassFilteredGlobalTable,
                                             typename std::conditional<kFilter == 1, FilteredGlobalTable, TaggedGlobalTable>::type>::type;
 #else
-    static_assert(kForm == 2 && kFilter == 1, "the product ships the bulk form behind the slot filter; other forms need -DSNAPPY_ABLATION");
+    static_assert((kForm == 2 || kForm == 3) && kFilter == 1, "the product ships the bulk and stream forms behind the slot filter; other forms need -DSNAPPY_ABLATION");
     using Table = FilteredGlobalTable;
 #endif
     Table table;
@@ -1118,6 +1174,9 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
             compress_one_block_windowed<Table, kAhead>(in, start, in_len, n, slot, table, lane, bytes_out);
         else
 #endif
+        if constexpr (kForm == 3)
+            compress_one_block_stream<Table, kStreamSlotsGlobal>(in, start, in_len, n, slot, table, lane, bytes_out, (lds_bytes_t)dup_scratch);
+        else
             compress_one_block_bulk<Table, kAhead>(in, start, in_len, n, slot, table, lane, bytes_out, (lds_bytes_t)dup_scratch);
     }
 }

@@ -216,7 +216,7 @@ extern "C" {
 
 // Runs compress_blocks_kernel + scan + gather on the CPU emulator.  Returns stream length.
 // variant = kernel form (1 LDS table, 3 global table, 4 lane-per-block, 5 group) + 100 * look-ahead code
-// (0 = EMU_K1_AHEAD, 1 = off, 2 = 4, 3 = 8, 4 = 16, 5 = 64) + 1000 for the masked form, + 2000 for the bulk form (chunk = look-ahead, needs > 0),
+// (0 = EMU_K1_AHEAD, 1 = off, 2 = 4, 3 = 8, 4 = 16, 5 = 64) + 1000 for the masked form, + 2000 for the bulk form (chunk = look-ahead, needs > 0), + 3000 for the stream form,
 // + 10000 for the LDS slot filter in front of the global table, + 20000 for the tag-class filter (bulk form only)
 #define EMU_AHEAD_DISPATCH(code, CALL)                         \
     switch (code) {                                            \
@@ -268,7 +268,9 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
                 EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 2, 2>(
                                                    w, block_size, stride, tables.data(), &counter)));
             } else if (filtered) {
-                if (form == 2) {
+                if (form == 3) {
+                    snappy_hip::compress_blocks_global_table_kernel<64, 3, 1>(w, block_size, stride, tables.data(), &counter);
+                } else if (form == 2) {
                     EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 2, 1>(
                                                        w, block_size, stride, tables.data(), &counter)));
                 } else if (form == 1) {
@@ -308,7 +310,9 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
                 if (emu::bidx().x * 64 < nb)
                     snappy_hip::compress_blocks_lane_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, lane_tables.data(), 1);
             } else
-                if (form == 2) {
+                if (form == 3) {
+                    snappy_hip::compress_blocks_lds_table_kernel<64, 3>(w, block_size, stride, nullptr);
+                } else if (form == 2) {
                     EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_lds_table_kernel<(kA ? kA : 8), 2>(
                                                        w, block_size, stride, nullptr)));
                 } else if (masked) {
@@ -380,6 +384,15 @@ void emu_verify_index(const uint8_t* stream, uint64_t stream_len, uint64_t* offs
     snappy_hip::StreamDesc d{stream, stream_len, offsets, result, total_len, block_size, header_len, nb};
     emu::launch(1, 64, [&] { snappy_hip::verify_index_begin_kernel(&d, 1); });
     emu::launch(snappy_hip::kVerifyGroup, 256, [&] { snappy_hip::verify_index_kernel(&d, 1); });
+}
+
+// statistics of the stream form (snappy_k1_stream.hpp), cleared by the read
+void emu_stream_stats(unsigned long long* out)
+{
+    for (int i = 0; i < 16; ++i) {
+        out[i] = snappy_hip::g_stream_stats[i];
+        snappy_hip::g_stream_stats[i] = 0;
+    }
 }
 
 int emu_decompress(const uint8_t* stream, uint64_t stream_len, uint32_t total_len, uint32_t block_size, uint32_t header_len,

@@ -44,8 +44,8 @@ def test_emulated_long_runs_and_split_copies():
 
 
 # compress variant = kernel form + 100 * look-ahead code (1 = off, 2 = 4, 3 = 8, 4 = 16, 5 = 64 positions)
-# + 1000 for the masked form, + 2000 for the bulk form, + 10000 for the LDS slot filter (see emu_runtime.cpp)
-@pytest.mark.parametrize("cv,dv", [(6, 3), (2501, 3), (12503, 3),                                 # the shipped forms
+# + 1000 for the masked form, + 2000 for the bulk form, + 3000 for the stream form, + 10000 for the LDS slot filter (see emu_runtime.cpp)
+@pytest.mark.parametrize("cv,dv", [(6, 3), (2501, 3), (12503, 3), (3501, 3), (13503, 3),          # the shipped forms (35xx: stream form)
                                    (1, 0), (4, 0), (5, 1), (103, 1), (403, 1), (1503, 1), (1501, 0),    # a sample of csrc/ablation/
                                    (2403, 1), (10503, 1), (22503, 1)])
 def test_emulated_other_variants(cv, dv):
@@ -163,3 +163,40 @@ def test_emulated_decoder_on_random_element_streams(flavour):
         total, got_bs, hdr = oracle.read_header(stream)
         st, out = emu.decompress(stream, total, got_bs, hdr)
         assert st == 0 and out == plain, (flavour, seed, bs)
+
+
+_STREAM_STRESS = """
+import sys
+sys.path.insert(0, sys.argv[1])
+import datagen, emu_lib as emu, oracle_lib as oracle
+from conftest import golden_bytes
+text = golden_bytes("plrabn12.txt")
+cases = [golden_bytes("terror2.txt")[:70000], datagen.text_random_interleave(text, 50000), datagen.records(50000), datagen.low_entropy(30000),
+         datagen.lz_structured(50000, 7), datagen.zeros(9000), datagen.periodic(9000, 5), b"abcd" + bytes(40000)]
+cases += [d[:12000] for _, d in datagen.edge_cases(text)]
+for data in cases:
+    for bs in (32768, 4097, 65535, 700):
+        if bs < 4096 and len(data) > 20000:
+            continue
+        ref = oracle.compress(data, bs)
+        for cv in (3501, 13503):
+            assert emu.compress(data, bs, cv) == ref, (len(data), bs, cv)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("unordered", [False, True])
+def test_emulated_stream_form(unordered):
+    """K1's stream form (snappy_k1_stream.hpp), LDS-table and global-table kernels, against the oracle: windows taken by the
+    pipeline, sent back to the bulk form (stride > 1, block tails), copies of 64+ bytes taken in place, chains of equal
+    hashes.  EMU_LDS_UNORDERED=1 lets the emulator's fibers run analyse()'s LDS atomics in no particular order, which the
+    kernel must detect and answer with the race tables of the bulk form."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    if unordered:
+        env["EMU_LDS_UNORDERED"] = "1"
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-c", _STREAM_STRESS, here], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
