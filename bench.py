@@ -138,6 +138,14 @@ class Batch:
                  result=self.results[2 * i:2 * i + 2], total_len=self.n[i], block_size=BLOCK_SIZE,
                  header_len=self.hdr[i], num_blocks=self.nb[i]) for i in range(self.count)]) if self.count else None
         self.d_meta = torch.zeros(3 * max(1, self.count), dtype=torch.int64, device="cuda")   # stream_len, result[0..1]
+        # "stream alone" mode (a decoder that is handed nothing but the framed streams, snappy_decompress.c:306-341): the
+        # size chains are walked on the device, all streams of the rank in ONE launch, into offsets of their own
+        self.walk_offsets = [torch.zeros(nb + 1, dtype=torch.int64, device="cuda") for nb in self.nb]
+        self.walk_results = torch.zeros(2 * max(1, self.count), dtype=torch.int32, device="cuda")
+        self.walk_descs = shb.make_stream_descs([
+            dict(stream=self.streams[i], stream_len=0, block_offsets=self.walk_offsets[i],
+                 result=self.walk_results[2 * i:2 * i + 2], total_len=self.n[i], block_size=BLOCK_SIZE,
+                 header_len=self.hdr[i], num_blocks=self.nb[i]) for i in range(self.count)]) if self.count else None
         self.fallback_walks = 0
         self.steps_run = 0
         self.groups = max(1, min(groups, self.count))
@@ -155,10 +163,13 @@ class Batch:
         e1.record()
         self.kernel_events[key].append((e0, e1))
 
-    def step(self, record=False):
+    def step(self, record=False, stream_alone=False):
         """Everything is enqueued without a host round trip: the stream lengths stay on the device (the decoder reads them
         there), and the containers go through in `groups` launches so that the decode of group g (second stream) runs
-        underneath the compression of group g+1.  The host reads the index check results once, at the end."""
+        underneath the compression of group g+1.  The host reads the index check results once, at the end.
+        stream_alone: the decoder gets nothing from the compressor but the framed streams -- the block index comes from the
+        serial walk of each stream's size chain (ONE index_streams launch over the group's streams) instead of the
+        compressor's offsets checked link by link."""
         shb, torch = self.shb, self.torch
         if not self.count:
             return
@@ -175,12 +186,19 @@ class Batch:
             for i in range(lo, hi):
                 shb.compact(self.n[i], self.wss[i], self.streams[i])
                 at = STREAM_DESC_BYTES * i + 8                   # descriptor field stream_len
-                self.descs[at:at + 8].copy_(self.wss[i].stream_len.view(torch.uint8), non_blocking=True)
+                (self.walk_descs if stream_alone else self.descs)[at:at + 8].copy_(self.wss[i].stream_len.view(torch.uint8),
+                                                                                   non_blocking=True)
                 self.d_meta[3 * i:3 * i + 1].copy_(self.wss[i].stream_len, non_blocking=True)
-            # ---- index: the compressor's offsets, checked link by link against the size chain of each stream ----
-            shb.verify_index(self.descs[STREAM_DESC_BYTES * lo:STREAM_DESC_BYTES * hi], hi - lo)
+            if stream_alone:
+                # ---- index: the size chains of the group's streams walked on the device, one launch (:317-340) ----
+                shb.index_streams(self.walk_descs[STREAM_DESC_BYTES * lo:STREAM_DESC_BYTES * hi], hi - lo)
+                offs = self.walk_offsets
+            else:
+                # ---- index: the compressor's offsets, checked link by link against the size chain of each stream ----
+                shb.verify_index(self.descs[STREAM_DESC_BYTES * lo:STREAM_DESC_BYTES * hi], hi - lo)
+                offs = [ws.offsets for ws in self.wss]
             # ---- decompress: ONE K2 launch over the group's streams, beside the next group's K1 ----
-            djobs = [(self.streams[i], self.wss[i].stream_len, self.wss[i].offsets, self.n[i], self.outs[i], self.status[i])
+            djobs = [(self.streams[i], self.wss[i].stream_len, offs[i], self.n[i], self.outs[i], self.status[i])
                      for i in range(lo, hi)]
             last = g == self.groups - 1
             side = main if last else self.side_streams[g % len(self.side_streams)]
@@ -192,10 +210,12 @@ class Batch:
                 self.group_done[g].record(side)
         for g in range(self.groups - 1):
             main.wait_event(self.group_done[g])
-        self.d_meta.view(self.count, 3)[:, 1:3].copy_(self.results.view(-1, 2)[:self.count])
+        self.d_meta.view(self.count, 3)[:, 1:3].copy_((self.walk_results if stream_alone else self.results).view(-1, 2)[:self.count])
         meta = self.d_meta.cpu().tolist()                         # the only host read of the step, after everything is enqueued
         self.stream_lens = [int(meta[3 * i]) for i in range(self.count)]
         for i in range(self.count):
+            if stream_alone and (meta[3 * i + 1] != 0 or meta[3 * i + 2] != self.nb[i]):
+                raise RuntimeError(f"container {i}: the size chain of the compressed stream is broken")
             if meta[3 * i + 1] != 0 or meta[3 * i + 2] != self.nb[i]:
                 # not expected for our own streams: walk the chain serially and decode that stream again
                 self.fallback_walks += 1
@@ -292,8 +312,8 @@ def host_cpu_info():
 
 def cpu_baseline(batch, torch, gpu_stream_bytes):
     """Oracle (CPU restatement of the reference host path) timed on this box's host cores, on a bounded sample of the same
-    workload: container 0 of rank 0.  All buffers are allocated and touched before the clock starts; a timed call is one
-    pthread launch -- per-block codec over contiguous block ranges + a parallel concat (oracle_mt_*).  Thread counts
+    workload: container 0 of rank 0.  All buffers are allocated and touched before the clock starts; a timed call is a
+    pthread launch per phase -- per-block codec over contiguous block ranges, then a parallel concat (oracle_mt_*).  Thread counts
     tried: every core the process may run on, and (when a cgroup CPU quota is set) the quota; the better one is `value`.
     Plus the first 64 MiB on one core, the reference's own (single-threaded) mode."""
     import numpy as np
@@ -377,6 +397,8 @@ def main():
                     help="launch groups per step: the decode of group g runs on a second stream underneath the compression of "
                          "group g+1 (1 = strictly compress-all then decompress-all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream-alone", action="store_true",
+                    help="skip the second timed region (the same steps with the block index walked from the streams alone)")
     ap.add_argument("--no-preverify", action="store_true",
                     help="skip the extra round trip through the serial size-chain walk before the timed steps (its per-container "
                          "launches would mix with the batched ones in a rocprofv3 --stats average); the timed path itself is "
@@ -433,12 +455,29 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ok = ok and batch.verify_last_step()
+    # ---- the same K steps with a decoder that starts from the streams alone (its own timed region, reported beside `value`) ----
+    elapsed_alone = None
+    if not args.no_stream_alone:
+        batch.step(stream_alone=True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            batch.step(stream_alone=True)
+        fence()
+        elapsed_alone = time.perf_counter() - t0
+        ok = ok and batch.verify_last_step()
+        for i in range(batch.count):                              # the walk found what the compressor's scan wrote
+            ok = ok and torch.equal(batch.walk_offsets[i][:batch.nb[i]], batch.wss[i].offsets[:batch.nb[i]])
     gpu_stream0 = bytes(batch.streams[0][:batch.stream_lens[0]].cpu().numpy()) if want_cpu else b""   # as the timed steps left it
 
     local_bytes = args.steps * sum(batch.n)
     local_comp = args.steps * sum(batch.stream_lens)
     secs, tot_bytes, tot_comp = reduce_results(elapsed, local_bytes, local_comp, dist,
                                                device="cuda" if backend == "nccl" else "cpu")
+    secs_alone = None
+    if elapsed_alone is not None:
+        secs_alone, _, _ = reduce_results(elapsed_alone, local_bytes, local_comp, dist,
+                                          device="cuda" if backend == "nccl" else "cpu")
 
     if rank == 0:
         c_ms = batch.kernel_ms("compress")
@@ -484,14 +523,24 @@ def main():
             "space_saving": round(1.0 - tot_comp / tot_bytes, 6),
             "compress_kernel_GBps": round(u / (c_ms * 1e-3) / 1e9, 3),
             "decompress_kernel_GBps": round(u / (d_ms * 1e-3) / 1e9, 3),
-            "index": {"mode": "compressor's offsets verified against the size chain (snappy_hip_verify_index)",
+            # the same steps with the block index taken from the streams alone: ONE snappy_hip_index_streams launch walks the
+            # size chains of all the rank's streams inside the step (snappy_decompress.c:306-341), nothing but the framed
+            # streams crosses from the compressor to the decoder
+            "value_from_stream_alone": round(tot_bytes / secs_alone / 1e9, 4) if secs_alone else None,
+            "ms_per_step_from_stream_alone": round(secs_alone / args.steps * 1e3, 3) if secs_alone else None,
+            "index": {"mode": "value: the compressor's offsets verified against the size chain, every link in parallel "
+                              "(snappy_hip_verify_index); value_from_stream_alone: the chain walked on the device, all streams "
+                              "of the rank in one launch (snappy_hip_index_streams)",
                       "fallback_serial_walks": batch.fallback_walks,
                       "serial_walk_ms_container0": round(batch.walk_ms(), 3)},
             "roofline": {"bound": "hbm", "kernel": "K1 = compress_blocks_global_table_kernel + compress_blocks_lds_table_kernel "
                                                    "(co-running pair, one launch over the rank's containers)",
                          "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6),
-                         "traffic": traffic, "lds_table_block_share": round(share, 4),
+                         "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json (offline rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of each K1 "
+                                           "form alone, bytes per input byte) x this run's block share of the two forms",
+                         "lds_table_block_share": round(share, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(c_ms, 4),
                          "decompress_kernel": {"achieved": round(d_algo / (d_ms * 1e-3) / 1e9, 3),
                                                "frac": round(d_algo / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),

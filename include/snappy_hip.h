@@ -29,6 +29,13 @@
 #include <stdint.h>
 #include <stddef.h>
 
+/* The library is built with -fvisibility=hidden: the functions declared in this header are its whole dynamic symbol table. */
+#if defined(__GNUC__)
+#define SNAPPY_HIP_API __attribute__((visibility("default")))
+#else
+#define SNAPPY_HIP_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -76,7 +83,7 @@ struct program_runtime {
  * Uses SNAPPY_HIP_NUM_GPUS devices (env, default: all visible), contiguous block ranges
  * per device (snappy_compress.c:494-520), host-side concat of per-device outputs.
  */
-snappy_status snappy_compress_gpu(struct host_buffer_context *input, struct host_buffer_context *output,
+SNAPPY_HIP_API snappy_status snappy_compress_gpu(struct host_buffer_context *input, struct host_buffer_context *output,
                                   uint32_t block_size, struct program_runtime *runtime);
 
 /*
@@ -88,7 +95,7 @@ snappy_status snappy_compress_gpu(struct host_buffer_context *input, struct host
  * Stricter than the host decoder: a block that overruns its compressed size, its output
  * window, or references bytes before its own start yields SNAPPY_INVALID_INPUT.
  */
-snappy_status snappy_decompress_gpu(struct host_buffer_context *input, struct host_buffer_context *output,
+SNAPPY_HIP_API snappy_status snappy_decompress_gpu(struct host_buffer_context *input, struct host_buffer_context *output,
                                     struct program_runtime *runtime);
 
 /* ---- 2. resident API ----------------------------------------------------- */
@@ -119,27 +126,27 @@ typedef struct snappy_hip_stream_desc {
 
 /* Page-locked host memory for callers that want PCIe-rate copies through the drop-in pair (the CLI reads its
  * input file straight into such a buffer).  NULL on failure. */
-void *snappy_hip_host_alloc(size_t bytes);
-void snappy_hip_host_free(void *p);
+SNAPPY_HIP_API void *snappy_hip_host_alloc(size_t bytes);
+SNAPPY_HIP_API void snappy_hip_host_free(void *p);
 
-int snappy_hip_device_count(void);
-int snappy_hip_set_device(int device);
-const char *snappy_hip_last_error(void);
+SNAPPY_HIP_API int snappy_hip_device_count(void);
+SNAPPY_HIP_API int snappy_hip_set_device(int device);
+SNAPPY_HIP_API const char *snappy_hip_last_error(void);
 /* name of the code-object architecture this library was built for ("gfx950") */
-const char *snappy_hip_arch(void);
+SNAPPY_HIP_API const char *snappy_hip_arch(void);
 
 /* Bytes reserved per block in the slot buffer: 16-byte multiple >= 4 + 32 + bs + bs/6
  * (u32 prefix + snappy_max_compressed_length, snappy_compress.c:55-60). */
-uint32_t snappy_hip_slot_stride(uint32_t block_size);
-uint64_t snappy_hip_num_blocks(uint64_t input_len, uint32_t block_size);
+SNAPPY_HIP_API uint32_t snappy_hip_slot_stride(uint32_t block_size);
+SNAPPY_HIP_API uint64_t snappy_hip_num_blocks(uint64_t input_len, uint32_t block_size);
 /* Upper bound of the framed stream for input_len bytes (header + all slots' payload). */
-uint64_t snappy_hip_stream_bound(uint64_t input_len, uint32_t block_size);
+SNAPPY_HIP_API uint64_t snappy_hip_stream_bound(uint64_t input_len, uint32_t block_size);
 /* Writes varint(total_len) varint(block_size) (snappy_compress.c:461-465) to a HOST buffer
  * of >= 10 bytes; returns header length. */
-uint32_t snappy_hip_write_header(uint8_t *dst, uint32_t total_len, uint32_t block_size);
+SNAPPY_HIP_API uint32_t snappy_hip_write_header(uint8_t *dst, uint32_t total_len, uint32_t block_size);
 /* Parses the two header varints from a HOST buffer (snappy_decompress.c:193-198, :220-225);
  * returns header length, 0 if malformed. */
-uint32_t snappy_hip_parse_header(const uint8_t *src, uint64_t avail, uint32_t *total_len, uint32_t *block_size);
+SNAPPY_HIP_API uint32_t snappy_hip_parse_header(const uint8_t *src, uint64_t avail, uint32_t *total_len, uint32_t *block_size);
 
 /*
  * K1: compress every block of d_in independently (semantics of compress_block,
@@ -153,12 +160,12 @@ uint32_t snappy_hip_parse_header(const uint8_t *src, uint64_t avail, uint32_t *t
  * instead (lower occupancy, same bytes).  After the launch, the u32 at byte 16 of the scratch holds the number
  * of blocks that were compressed by the LDS-table wavefronts of the concurrent launch (statistics only).
  */
-uint64_t snappy_hip_compress_scratch_bytes(void);
+SNAPPY_HIP_API uint64_t snappy_hip_compress_scratch_bytes(void);
 /* Wavefronts per CU whose hash table lives in LDS in a default K1 launch at this block size (the table is sized by the
  * block size, so small blocks get more of them: reference dpu_compress.c:16, :472-476 sizes its table to the tasklet's
  * memory the same way).  For the block-size sweep's occupancy column. */
-uint32_t snappy_hip_k1_lds_waves_per_cu(uint32_t block_size);
-int snappy_hip_compress_blocks(const uint8_t *d_in, uint64_t input_len, uint32_t block_size,
+SNAPPY_HIP_API uint32_t snappy_hip_k1_lds_waves_per_cu(uint32_t block_size);
+SNAPPY_HIP_API int snappy_hip_compress_blocks(const uint8_t *d_in, uint64_t input_len, uint32_t block_size,
                                uint8_t *d_slots, uint32_t slot_stride, uint32_t *d_block_bytes,
                                void *d_scratch, uint64_t scratch_bytes, void *stream);
 
@@ -176,7 +183,7 @@ struct snappy_hip_compress_item {
     void *d_slots;              /* num_blocks(input_len) * slot_stride bytes, 16-byte aligned */
     void *d_block_bytes;        /* num_blocks(input_len) u32 */
 };
-int snappy_hip_compress_blocks_batch(const struct snappy_hip_compress_item *items, uint32_t count, uint32_t block_size,
+SNAPPY_HIP_API int snappy_hip_compress_blocks_batch(const struct snappy_hip_compress_item *items, uint32_t count, uint32_t block_size,
                                      uint32_t slot_stride, void *d_scratch, uint64_t scratch_bytes, void *stream);
 
 /*
@@ -185,7 +192,7 @@ int snappy_hip_compress_blocks_batch(const struct snappy_hip_compress_item *item
  * d_stream; [num_blocks] = stream length, also stored to *d_stream_len if non-NULL).
  * This is the device-side form of the per-tasklet fwrite concat, snappy_compress.c:697-704.
  */
-int snappy_hip_compact(const uint8_t *d_slots, uint32_t slot_stride, const uint32_t *d_block_bytes,
+SNAPPY_HIP_API int snappy_hip_compact(const uint8_t *d_slots, uint32_t slot_stride, const uint32_t *d_block_bytes,
                        uint64_t input_len, uint32_t block_size,
                        uint8_t *d_stream, uint64_t *d_offsets, uint64_t *d_stream_len, void *stream);
 
@@ -193,7 +200,7 @@ int snappy_hip_compact(const uint8_t *d_slots, uint32_t slot_stride, const uint3
  * Walk the u32 size chains of `count` streams (one wavefront each), the device form of the
  * host pre-scan snappy_decompress.c:317-340.  d_descs: device array of `count` descriptors.
  */
-int snappy_hip_index_streams(const snappy_hip_stream_desc *d_descs, uint32_t count, void *stream);
+SNAPPY_HIP_API int snappy_hip_index_streams(const snappy_hip_stream_desc *d_descs, uint32_t count, void *stream);
 
 /*
  * Check candidate indexes against the size chains of `count` streams, every link in parallel: a caller that already
@@ -204,14 +211,14 @@ int snappy_hip_index_streams(const snappy_hip_stream_desc *d_descs, uint32_t cou
  * result[0] = SNAPPY_HIP_BLOCK_OK when every link holds, SNAPPY_HIP_BLOCK_INVALID otherwise (then use
  * snappy_hip_index_streams, which needs no candidate); result[1] = number of links that hold.
  */
-int snappy_hip_verify_index(const snappy_hip_stream_desc *d_descs, uint32_t count, void *stream);
+SNAPPY_HIP_API int snappy_hip_verify_index(const snappy_hip_stream_desc *d_descs, uint32_t count, void *stream);
 
 /*
  * K2: decode every block (semantics of snappy_decompress.c:232-285 on well-formed streams,
  * strict otherwise).  Block i is read at d_stream + d_block_offsets[i] and decoded to
  * d_out + i*block_size; d_status[i] = SNAPPY_HIP_BLOCK_*.
  */
-int snappy_hip_decompress_blocks(const uint8_t *d_stream, uint64_t stream_len, const uint64_t *d_block_offsets,
+SNAPPY_HIP_API int snappy_hip_decompress_blocks(const uint8_t *d_stream, uint64_t stream_len, const uint64_t *d_block_offsets,
                                  uint64_t total_len, uint32_t block_size,
                                  uint8_t *d_out, uint32_t *d_status, void *stream);
 
@@ -232,7 +239,7 @@ struct snappy_hip_decompress_item {
     void *d_out;                   /* device: total_len bytes                               */
     void *d_status;                /* device: num_blocks(total_len) u32                     */
 };
-int snappy_hip_decompress_blocks_batch(const struct snappy_hip_decompress_item *items, uint32_t count, uint32_t block_size,
+SNAPPY_HIP_API int snappy_hip_decompress_blocks_batch(const struct snappy_hip_decompress_item *items, uint32_t count, uint32_t block_size,
                                        void *stream);
 
 #ifdef __cplusplus

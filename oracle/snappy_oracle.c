@@ -596,7 +596,6 @@ struct oracle_mt_ctx {
 	uint64_t *region_len;                 /* bytes each thread produced */
 	uint64_t *region_at;                  /* where each thread's bytes go in the stream */
 	uint64_t *offsets;                    /* decompress: block offsets */
-	pthread_barrier_t barrier;
 };
 
 struct mt2_job {
@@ -630,7 +629,7 @@ void *oracle_mt_create(uint64_t max_n, uint32_t block_size, int nthreads)
 	c->region_len = (uint64_t *)calloc(nthreads, sizeof(uint64_t));
 	c->region_at = (uint64_t *)calloc(nthreads, sizeof(uint64_t));
 	c->offsets = (uint64_t *)malloc((c->nblocks_max + 1) * sizeof(uint64_t));
-	if (!c->regions || !c->region_len || !c->region_at || !c->offsets || pthread_barrier_init(&c->barrier, NULL, nthreads)) {
+	if (!c->regions || !c->region_len || !c->region_at || !c->offsets) {
 		free(c->regions);
 		free(c->region_len);
 		free(c->region_at);
@@ -648,7 +647,6 @@ void oracle_mt_destroy(void *ctx)
 	struct oracle_mt_ctx *c = (struct oracle_mt_ctx *)ctx;
 	if (!c)
 		return;
-	pthread_barrier_destroy(&c->barrier);
 	free(c->regions);
 	free(c->region_len);
 	free(c->region_at);
@@ -656,6 +654,24 @@ void oracle_mt_destroy(void *ctx)
 	free(c);
 }
 
+/* Runs fn over jobs[0..count): one pthread each; a job whose thread cannot be created (thread / pid limits of the
+ * container) runs on the calling thread instead, so a call never hangs or loses work.  No barriers: phases are separate
+ * launches. */
+static void mt2_run(struct mt2_job *jobs, int count, void *(*fn)(void *))
+{
+	pthread_t tid[256];
+	unsigned char started[256];
+	for (int t = 0; t < count; t++)
+		started[t] = pthread_create(&tid[t], NULL, fn, &jobs[t]) == 0;
+	for (int t = 0; t < count; t++)
+		if (!started[t])
+			fn(&jobs[t]);
+	for (int t = 0; t < count; t++)
+		if (started[t])
+			pthread_join(tid[t], NULL);
+}
+
+/* phase 1: the thread's contiguous block range into its own region */
 static void *mt2_compress_worker(void *arg)
 {
 	struct mt2_job *j = (struct mt2_job *)arg;
@@ -672,16 +688,15 @@ static void *mt2_compress_worker(void *arg)
 		put += oracle_compress_block(j->src + start, todo, region + put, table);
 	}
 	c->region_len[j->t] = put;
-	pthread_barrier_wait(&c->barrier);
-	if (j->t == 0) {
-		uint64_t at = j->hdr_len;
-		for (int t = 0; t < c->nthreads; t++) {
-			c->region_at[t] = at;
-			at += c->region_len[t];
-		}
-	}
-	pthread_barrier_wait(&c->barrier);
-	memcpy(j->dst + c->region_at[j->t], region, put);
+	return NULL;
+}
+
+/* phase 2: the parallel concat (region_at is the prefix sum of the region lengths) */
+static void *mt2_concat_worker(void *arg)
+{
+	struct mt2_job *j = (struct mt2_job *)arg;
+	struct oracle_mt_ctx *c = j->c;
+	memcpy(j->dst + c->region_at[j->t], c->regions + (uint64_t)j->t * c->region_stride, c->region_len[j->t]);
 	return NULL;
 }
 
@@ -693,15 +708,17 @@ uint64_t oracle_mt_compress(void *ctx, const uint8_t *src, uint64_t n, uint8_t *
 		return 0;
 	uint64_t nblocks = (n + c->block_size - 1) / c->block_size;
 	uint64_t hdr = oracle_write_header(dst, (uint32_t)n, c->block_size);
-	pthread_t tid[256];
 	struct mt2_job jobs[256];
-	for (int t = 0; t < c->nthreads; t++) {
-		jobs[t] = (struct mt2_job){ .c = c, .t = t, .src = src, .n = n, .dst = dst, .hdr_len = hdr, .nblocks = nblocks };
-		pthread_create(&tid[t], NULL, mt2_compress_worker, &jobs[t]);
-	}
 	for (int t = 0; t < c->nthreads; t++)
-		pthread_join(tid[t], NULL);
-	return c->region_at[c->nthreads - 1] + c->region_len[c->nthreads - 1];
+		jobs[t] = (struct mt2_job){ .c = c, .t = t, .src = src, .n = n, .dst = dst, .hdr_len = hdr, .nblocks = nblocks };
+	mt2_run(jobs, c->nthreads, mt2_compress_worker);
+	uint64_t at = hdr;
+	for (int t = 0; t < c->nthreads; t++) {
+		c->region_at[t] = at;
+		at += c->region_len[t];
+	}
+	mt2_run(jobs, c->nthreads, mt2_concat_worker);
+	return at;
 }
 
 static void *mt2_decompress_worker(void *arg)
@@ -736,17 +753,13 @@ int oracle_mt_decompress(void *ctx, const uint8_t *src, uint64_t n, uint8_t *out
 	uint64_t nblocks = ((uint64_t)total + bs - 1) / bs;
 	if (oracle_index_blocks(src, n, c->offsets, nblocks) != (int64_t)nblocks)
 		return ORACLE_INVALID_INPUT;
-	pthread_t tid[256];
 	struct mt2_job jobs[256];
-	for (int t = 0; t < c->nthreads; t++) {
+	for (int t = 0; t < c->nthreads; t++)
 		jobs[t] = (struct mt2_job){ .c = c, .t = t, .src = src, .n = n, .nblocks = nblocks, .out = out, .out_len = total };
-		pthread_create(&tid[t], NULL, mt2_decompress_worker, &jobs[t]);
-	}
+	mt2_run(jobs, c->nthreads, mt2_decompress_worker);
 	int status = ORACLE_OK;
-	for (int t = 0; t < c->nthreads; t++) {
-		pthread_join(tid[t], NULL);
+	for (int t = 0; t < c->nthreads; t++)
 		if (jobs[t].status != ORACLE_OK)
 			status = jobs[t].status;
-	}
 	return status;
 }

@@ -14,12 +14,14 @@
 #include <algorithm>
 #include <atomic>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/snappy_hip.h"
+#include "shard_devices.hpp"
 #include "snappy_kernels.hpp"
 
 namespace {
@@ -257,34 +259,42 @@ int env_int(const char* name, int fallback)
 // 33 KiB from -b 16384 up -- there the measured optimum is 3 per CU beside 20 global-table wavefronts -- but 17 KiB at
 // -b 8192, 9 KiB at -b 4096, ...: then as many as the 160 KiB hold (at most 28, leaving wave slots for the global-table
 // form to mop up), since an LDS-table wavefront costs no table traffic at all.
+// LDS is handed out in blocks; the block size of gfx950 is not documented in the guides of this repo, so budgets round
+// every allocation up to 1 KiB (a multiple of every granule CDNA parts have used)
+uint32_t lds_alloc_bytes(uint32_t bytes) { return (bytes + 1023u) & ~1023u; }
+
 uint32_t default_lds_waves_per_cu(uint32_t block_size)
 {
-    const uint32_t per_wave = snappy_hip::lds_table_kernel_lds_bytes(block_size, true);
+    const uint32_t per_wave = lds_alloc_bytes(env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream) & 1
+                                                  ? snappy_hip::lds_table_stream_lds_bytes(block_size)
+                                                  : snappy_hip::lds_table_kernel_lds_bytes(block_size, true));
     if (per_wave > (24u << 10)) return kDefaultLdsWaves / 256;
-    return std::min<uint32_t>(28u, (160u << 10) / per_wave);
+    // small tables: as many LDS-table wavefronts as fit beside at least 8 global-table wavefronts per CU (4 KiB each at
+    // most), which mop up what the LDS-table ones leave; at most 24 of the 32 wave slots
+    return std::min<uint32_t>(24u, ((160u << 10) - 8u * (4u << 10)) / per_wave);
 }
 
 // Number of shards the drop-in pair splits a file into: SNAPPY_HIP_NUM_GPUS (default: every visible device).
 // SNAPPY_HIP_OVERSUBSCRIBE=1 (test hook) allows more shards than devices; shard g then runs on device
-// g % device_count, so the sharding and host-side concat paths can be exercised on a one-GPU box.
-int g_physical_devices = 1;
-int g_base_device = 0;      // the caller's current device when the drop-in pair was entered: shard 0 runs there
-
-int requested_gpus()
+// (base + g) % device_count, so the sharding and host-side concat paths can be exercised on a one-GPU box.
+// (ShardDevices -- per call: where the shards of THIS call of the drop-in pair run -- lives in shard_devices.hpp)
+ShardDevices requested_devices()
 {
+    ShardDevices d;
     int have = 0;
-    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return 0;
-    g_physical_devices = have;
+    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return d;
+    d.physical = have;
+    int cur = 0;
+    if (hipGetDevice(&cur) == hipSuccess && cur > 0 && cur < have) d.base = cur;
     const char* env = getenv("SNAPPY_HIP_NUM_GPUS");
     if (env && *env) {
         const int want = atoi(env);
         const bool over = env_int("SNAPPY_HIP_OVERSUBSCRIBE", 0) != 0;
         if (want >= 1 && (want < have || (over && want <= 64))) have = want;
     }
-    return have;
+    d.shards = have;
+    return d;
 }
-
-hipError_t set_shard_device(int shard) { return hipSetDevice((g_base_device + shard) % g_physical_devices); }
 
 // The drop-in pair leaves the calling thread's current device as it found it (its shard threads are its own).
 struct CallerDevice {
@@ -292,7 +302,6 @@ struct CallerDevice {
     CallerDevice()
     {
         if (hipGetDevice(&dev) != hipSuccess) dev = -1;
-        g_base_device = dev > 0 ? dev : 0;
     }
     ~CallerDevice()
     {
@@ -384,7 +393,8 @@ int k1_forms_from_env(K1Forms* f)
     f->extra_lds = (uint32_t)env_int("SNAPPY_HIP_EXTRA_LDS", 0);             // occupancy ablation
 #else
     for (const char* name : {"SNAPPY_HIP_K1_AHEAD", "SNAPPY_HIP_K1_AHEAD_LDS", "SNAPPY_HIP_K1_FORM", "SNAPPY_HIP_K1_FORM_LDS",
-                             "SNAPPY_HIP_K1_FILTER", "SNAPPY_HIP_EXTRA_LDS", "SNAPPY_HIP_LANES_PER_BLOCK", "SNAPPY_HIP_GROUP_WAVES"})
+                             "SNAPPY_HIP_K1_FILTER", "SNAPPY_HIP_EXTRA_LDS", "SNAPPY_HIP_LANES_PER_BLOCK", "SNAPPY_HIP_GROUP_WAVES",
+                             "SNAPPY_HIP_PAIR_PER_CU"})
         if (getenv(name))
             return fail(SNAPPY_HIP_ERR_ARG, std::string(name) + " selects an ablation kernel; this library was built without them "
                                                                 "(python tools/build_ablation.py builds libsnappy_hip_ablation.so)");
@@ -423,12 +433,6 @@ void launch_global_table_kernel(const K1Forms& f, uint32_t grid, hipStream_t st,
     if (env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream) & 2)
         hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 3, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
                            slot_stride, tables, counter);
-    else if (env_int("SNAPPY_HIP_GT_CHUNK", 64) == 32)
-        hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<32, 2, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
-                           slot_stride, tables, counter);
-    else if (env_int("SNAPPY_HIP_GT_CHUNK", 64) == 16)
-        hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<16, 2, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
-                           slot_stride, tables, counter);
     else
         hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 2, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
                            slot_stride, tables, counter);
@@ -446,7 +450,7 @@ extern "C" {
 void* snappy_hip_host_alloc(size_t bytes)
 {
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
         g_last_error = "hipHostMalloc failed";
         return nullptr;
     }
@@ -525,10 +529,12 @@ int snappy_hip_debug_prof(unsigned long long* out, int reset)
 uint32_t snappy_hip_k1_lds_waves_per_cu(uint32_t block_size)
 {
     if (!block_size_ok(block_size)) return 0;
+#ifdef SNAPPY_ABLATION
     if (const int pair = env_int("SNAPPY_HIP_PAIR_PER_CU", env_int("SNAPPY_HIP_LDS_WAVES", -1) >= 0 ? 0 : kDefaultPairPerCu)) {
         const uint32_t pair_lds = (snappy_hip::pair_lds_bytes(block_size) + 1023u) & ~1023u;
         return snappy_hip::kPairWaves * std::min<uint32_t>({(uint32_t)pair, kWaveSlotsPerCu / snappy_hip::kPairWaves, kLdsPerCu / pair_lds});
     }
+#endif
     const int forced = env_int("SNAPPY_HIP_LDS_WAVES", -1);
     return forced >= 0 ? ((uint32_t)forced + kCus - 1) / kCus : default_lds_waves_per_cu(block_size);
 }
@@ -630,6 +636,7 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
         HIP_TRY(hipStreamWaitEvent(st, cr->ev_end, 0));                // the caller's stream resumes when both are done
         return 0;
     };
+#ifdef SNAPPY_ABLATION   // round 2's two-wavefront LDS-table workgroups (csrc/ablation/k1_pair_kernel.hpp)
     const int pair_req = env_int("SNAPPY_HIP_PAIR_PER_CU", env_int("SNAPPY_HIP_LDS_WAVES", -1) >= 0 ? 0 : kDefaultPairPerCu);
     if (pair_req > 0) {
         // Workgroups of TWO wavefronts sharing one u16 table in LDS (compress_blocks_pair_kernel): 2 x table_entries_for(
@@ -658,22 +665,24 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
         HIP_TRY(hipGetLastError());
         return SNAPPY_HIP_OK;
     }
+#endif
     // One-wavefront LDS-table workgroups (the default): SNAPPY_HIP_LDS_WAVES of them run concurrently on the helper stream,
     // default_lds_waves_per_cu(block_size) per CU; both kernels draw blocks from the same counter, so the split balances itself.
     uint32_t lds_waves = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", (int)(default_lds_waves_per_cu(block_size) * kCus));
-    uint32_t waves;
+    if (nb < (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096)) lds_waves = 0;     // small inputs: one kernel is enough
+    uint32_t waves;                                                                        // (decided BEFORE the wave budget below)
     {
         const uint32_t lds_per_cu = (lds_waves + kCus - 1) / kCus;
-        const uint32_t lds_wave_bytes = ((k1_stream & 1) ? snappy_hip::lds_table_stream_lds_bytes(block_size)
-                                                         : snappy_hip::lds_table_kernel_lds_bytes(block_size, forms.form_lds != 0)) + forms.extra_lds;
+        const uint32_t lds_wave_bytes = lds_alloc_bytes(((k1_stream & 1) ? snappy_hip::lds_table_stream_lds_bytes(block_size)
+                                                                         : snappy_hip::lds_table_kernel_lds_bytes(block_size, forms.form_lds != 0)) +
+                                                        forms.extra_lds);
         uint32_t g_per_cu = kWaveSlotsPerCu > lds_per_cu ? kWaveSlotsPerCu - lds_per_cu : 0u;
         if (g_wave_bytes && lds_per_cu * lds_wave_bytes < kLdsPerCu)
-            g_per_cu = std::min(g_per_cu, (kLdsPerCu - lds_per_cu * lds_wave_bytes) / g_wave_bytes);
+            g_per_cu = std::min(g_per_cu, (kLdsPerCu - lds_per_cu * lds_wave_bytes) / lds_alloc_bytes(g_wave_bytes));
         waves = lds_waves + g_per_cu * kCus;
     }
     waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", (int)waves);
     if (waves > kGlobalTableWaves) waves = kGlobalTableWaves;
-    if (nb < (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096)) lds_waves = 0;     // small inputs: one kernel is enough
     if (lds_waves > waves / 2 && lds_waves < waves) {
         // small block sizes: most wavefronts have their table in LDS; the global-table form only mops up what is left
     } else if (lds_waves >= waves) {
@@ -825,12 +834,12 @@ static int launch_decompress(const snappy_hip::K2Batch& w, uint32_t block_size, 
         hipEvent_t ev_begin = cr->ev_begin, ev_end = cr->ev_end;
         HIP_TRY(hipEventRecord(ev_begin, st));
         HIP_TRY(hipStreamWaitEvent(helper, ev_begin, 0));
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, helper, w, block_size, counter);
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_element_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, helper, w, block_size, counter);
         HIP_TRY(hipEventRecord(ev_end, helper));
-        hipLaunchKernelGGL((snappy_hip::decompress_blocks_kernel<false, true>), dim3(glob_waves), dim3(64), 0, st, w, block_size, counter);
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel, dim3(glob_waves), dim3(64), 0, st, w, block_size, counter);
         HIP_TRY(hipStreamWaitEvent(st, ev_end, 0));
     } else if (lds_waves) {
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, st, w, block_size, counter);
+        hipLaunchKernelGGL(snappy_hip::decompress_blocks_element_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, st, w, block_size, counter);
     } else
 #else
     if ((getenv("SNAPPY_HIP_DECOMPRESS_VARIANT") && env_int("SNAPPY_HIP_DECOMPRESS_VARIANT", kDefaultDecompressVariant) != kDefaultDecompressVariant) ||
@@ -843,10 +852,10 @@ static int launch_decompress(const snappy_hip::K2Batch& w, uint32_t block_size, 
         const uint32_t glob = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nb, k2_cap), resident);
 #ifdef SNAPPY_ABLATION
         if (!env_int("SNAPPY_HIP_K2_BATCH", 1))       // round 1's element-at-a-time loop
-            hipLaunchKernelGGL((snappy_hip::decompress_blocks_kernel<false, false>), dim3(glob), dim3(64), 0, st, w, block_size, counter);
+            hipLaunchKernelGGL(snappy_hip::decompress_blocks_element_kernel<false>, dim3(glob), dim3(64), 0, st, w, block_size, counter);
         else
 #endif
-            hipLaunchKernelGGL((snappy_hip::decompress_blocks_kernel<false, true>), dim3(glob), dim3(64), 0, st, w, block_size, counter);
+            hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel, dim3(glob), dim3(64), 0, st, w, block_size, counter);
     }
     const hipError_t launched = hipGetLastError();
     if (int rc = work_counter_launched(wc, st)) return rc;       // after the join: the event covers both kernels
@@ -915,11 +924,13 @@ int snappy_hip_decompress_blocks_batch(const struct snappy_hip_decompress_item* 
     return SNAPPY_HIP_OK;
 }
 
+}  // extern "C"
+
 // ===========================================================================
 // drop-in pair (reference L2 signatures)
 // ===========================================================================
 
-namespace {
+namespace {   // (C++ linkage: an unnamed namespace inside extern "C" would still export unmangled names)
 
 // One pipeline stage unit of the overlapped drop-in pair: a contiguous run of blocks of a shard whose copy-in, kernels
 // and copy-out overlap those of its neighbours.
@@ -964,11 +975,23 @@ std::mutex* pipeline_mutex()
     return m;
 }
 
-int pipeline_streams(int shard, size_t chunks, PipelineStreams** out)
+// Cached per (device, shard): streams, events and the DMA queues behind them belong to the device they were created on, and
+// the shard-to-device mapping follows the caller's current device (ShardDevices), so shard g of one call and shard g of the
+// next may run on different devices; two shards on ONE device (SNAPPY_HIP_OVERSUBSCRIBE) run in different host threads at
+// the same time and must not share a set either.
+int pipeline_streams(int device, int shard, size_t chunks, PipelineStreams** out)
 {
-    static PipelineStreams per_shard[64];
-    if (shard < 0 || shard >= 64) return fail(SNAPPY_HIP_ERR_ARG, "shard index out of range");
-    PipelineStreams& p = per_shard[shard];                // shard g is only ever touched by the host thread driving shard g
+    static std::map<int, PipelineStreams*> cache;
+    static std::mutex cache_mutex;
+    if (shard < 0 || shard >= 64 || device < 0 || device >= 64) return fail(SNAPPY_HIP_ERR_ARG, "shard / device index out of range");
+    PipelineStreams* pp = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(cache_mutex);
+        PipelineStreams*& slot = cache[pipeline_stream_key(device, shard)];
+        if (!slot) slot = new PipelineStreams;               // never destroyed (threads may outlive statics)
+        pp = slot;
+    }
+    PipelineStreams& p = *pp;                            // one (device, shard) is only ever touched by the host thread driving that shard
     if (!p.in) {
         HIP_TRY(hipStreamCreateWithFlags(&p.in, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&p.run, hipStreamNonBlocking));
@@ -985,7 +1008,7 @@ int pipeline_streams(int shard, size_t chunks, PipelineStreams** out)
         // ... and the first asynchronous copy in either direction on a stream starts a DMA queue of its own (~8 ms)
         const size_t n = 256u << 10;
         void *h = nullptr, *d = nullptr;
-        HIP_TRY(hipHostMalloc(&h, n, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&h, n, hipHostMallocPortable));
         HIP_TRY(hipMalloc(&d, n));
         memset(h, 0, n);
         HIP_TRY(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, p.in));
@@ -1000,7 +1023,7 @@ int pipeline_streams(int shard, size_t chunks, PipelineStreams** out)
         p.h_len = nullptr;
         p.h_len_count = 0;
         const size_t want = std::max<size_t>(chunks, 64);
-        HIP_TRY(hipHostMalloc((void**)&p.h_len, want * sizeof(uint64_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&p.h_len, want * sizeof(uint64_t), hipHostMallocPortable));
         p.h_len_count = want;
     }
     *out = &p;
@@ -1105,26 +1128,28 @@ struct DecompressShard {
 // released everything in its timed "free" phase by then, and release() is idempotent).
 struct CompressCleanup {
     std::vector<CompressShard>& shards;
+    const ShardDevices& devs;
     ~CompressCleanup()
     {
         bool any = false;
         for (auto& s : shards) any = any || s.owns_anything();
         if (!any) return;
         for (size_t g = 0; g < shards.size(); ++g) {
-            if (set_shard_device((int)g) == hipSuccess) (void)hipDeviceSynchronize();
+            if (hipSetDevice(devs.device_of((int)g)) == hipSuccess) (void)hipDeviceSynchronize();
             shards[g].release();
         }
     }
 };
 struct DecompressCleanup {
     std::vector<DecompressShard>& shards;
+    const ShardDevices& devs;
     ~DecompressCleanup()
     {
         bool any = false;
         for (auto& s : shards) any = any || s.owns_anything();
         if (!any) return;
         for (size_t g = 0; g < shards.size(); ++g) {
-            if (set_shard_device((int)g) == hipSuccess) (void)hipDeviceSynchronize();
+            if (hipSetDevice(devs.device_of((int)g)) == hipSuccess) (void)hipDeviceSynchronize();
             shards[g].release();
         }
     }
@@ -1153,7 +1178,7 @@ int warm_up_device()
     HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel<64, 2, 1>)));
     HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_lds_table_kernel<64, 2>)));
     HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::gather_slots_kernel)));
-    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel<false, true>)));
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel)));
     CoRunResources* cr = nullptr;
     if (int rc = corun_resources(&cr)) return rc;
     WorkCounter c;
@@ -1171,7 +1196,7 @@ int warm_up_device()
     if (dev >= 0 && dev < 64 && !engines_started[dev]) {
         const size_t n = 1u << 20;
         void *h = nullptr, *d = nullptr;
-        HIP_TRY(hipHostMalloc(&h, n, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&h, n, hipHostMallocPortable));
         HIP_TRY(hipMalloc(&d, n));
         memset(h, 0, n);
         HIP_TRY(hipMemcpy(d, h, n, hipMemcpyHostToDevice));
@@ -1219,7 +1244,8 @@ snappy_status report(const char* where, int rc)
 // the last kernel, copy_out = what is left of the wall time.
 // ---------------------------------------------------------------------------
 snappy_status compress_pipelined(struct host_buffer_context* input, struct host_buffer_context* output, uint32_t block_size,
-                                 struct program_runtime* runtime, std::vector<CompressShard>& sh, int gpus, const uint8_t* hdr,
+                                 struct program_runtime* runtime, std::vector<CompressShard>& sh, int gpus, const ShardDevices& devs,
+                                 const uint8_t* hdr,
                                  uint32_t hdr_len, uint32_t stride, uint64_t chunk_blocks)
 {
     const uint64_t scratch_bytes = snappy_hip_compress_scratch_bytes();
@@ -1229,7 +1255,7 @@ snappy_status compress_pipelined(struct host_buffer_context* input, struct host_
     double t0 = now_seconds();
     int rc = for_each_device(gpus, [&](int g) -> int {
         CompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
+        HIP_TRY(hipSetDevice(devs.device_of(g)));
         if (!s.num_blocks) return 0;
         uint64_t stream_pool = 0, offsets_pool = 0;
         std::vector<BlockRange> ranges;
@@ -1274,11 +1300,11 @@ snappy_status compress_pipelined(struct host_buffer_context* input, struct host_
     // load (dpu_load, :541): code object, copy engines, and this shard's streams with their hardware queues
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
-        HIP_TRY(set_shard_device(g));
+        HIP_TRY(hipSetDevice(devs.device_of(g)));
         if (int r = warm_up_device()) return r;
         if (!sh[g].num_blocks) return 0;
         PipelineStreams* ps = nullptr;
-        if (int r = pipeline_streams(g, sh[g].chunks.size(), &ps)) return r;
+        if (int r = pipeline_streams(devs.device_of(g), g, sh[g].chunks.size(), &ps)) return r;
         sh[g].ps = *ps;
         return 0;
     });
@@ -1320,7 +1346,7 @@ snappy_status compress_pipelined(struct host_buffer_context* input, struct host_
             HIP_TRY(hipGetDevice(&here));
             for (int g2 = 0; g2 < gpus; ++g2) {
                 if (!sh[g2].num_blocks || !sh[g2].ps.out) continue;
-                HIP_TRY(set_shard_device(g2));
+                HIP_TRY(hipSetDevice(devs.device_of(g2)));
                 HIP_TRY(hipStreamSynchronize(sh[g2].ps.out));
             }
             HIP_TRY(hipSetDevice(here));
@@ -1340,7 +1366,7 @@ snappy_status compress_pipelined(struct host_buffer_context* input, struct host_
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         CompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
+        HIP_TRY(hipSetDevice(devs.device_of(g)));
         if (!s.num_blocks) return 0;
         const size_t n = s.chunks.size();
         auto copy_in = [&](size_t k) -> int {
@@ -1405,13 +1431,13 @@ snappy_status compress_pipelined(struct host_buffer_context* input, struct host_
         for (int g = 1; g < gpus && !rc; ++g) {
             CompressShard& s = sh[g];
             if (!s.num_blocks) continue;
-            if ((rc = (int)set_shard_device(g))) break;
+            if ((rc = (int)hipSetDevice(devs.device_of(g)))) break;
             for (auto& c : s.chunks)
                 if ((rc = copy_out_chunk(s, c))) break;
         }
         if (!rc)
             rc = for_each_device(gpus, [&](int g) -> int {
-                HIP_TRY(set_shard_device(g));
+                HIP_TRY(hipSetDevice(devs.device_of(g)));
                 if (g && sh[g].num_blocks) HIP_TRY(hipStreamSynchronize(sh[g].ps.out));
                 return 0;
             });
@@ -1427,7 +1453,7 @@ snappy_status compress_pipelined(struct host_buffer_context* input, struct host_
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         CompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
+        HIP_TRY(hipSetDevice(devs.device_of(g)));
         s.release();
         return 0;
     });
@@ -1450,13 +1476,14 @@ snappy_status compress_pipelined(struct host_buffer_context* input, struct host_
 // Decompress counterpart: sizes are known from the host pre-scan, so the whole pipeline is enqueued without a host
 // round trip; chunk k's plaintext goes straight into its range of output->buffer (snappy_decompress.c:463).
 snappy_status decompress_pipelined(const uint8_t* buf, uint64_t in_total, struct host_buffer_context* output,
-                                   struct program_runtime* runtime, std::vector<DecompressShard>& sh, int gpus, uint32_t bs,
+                                   struct program_runtime* runtime, std::vector<DecompressShard>& sh, int gpus, const ShardDevices& devs,
+                                   uint32_t bs,
                                    uint64_t total, uint64_t chunk_blocks)
 {
     double t0 = now_seconds();
     int rc = for_each_device(gpus, [&](int g) -> int {
         DecompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
+        HIP_TRY(hipSetDevice(devs.device_of(g)));
         if (!s.num_blocks) return 0;
         std::vector<BlockRange> ranges;
         split_blocks(s.num_blocks, chunk_blocks, ranges);
@@ -1482,11 +1509,11 @@ snappy_status decompress_pipelined(const uint8_t* buf, uint64_t in_total, struct
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         DecompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
+        HIP_TRY(hipSetDevice(devs.device_of(g)));
         if (int r = warm_up_device()) return r;
         if (!s.num_blocks) return 0;
         PipelineStreams* ps = nullptr;
-        if (int r = pipeline_streams(g, s.num_blocks + 1, &ps)) return r;   // page-locked home of the block offsets
+        if (int r = pipeline_streams(devs.device_of(g), g, s.num_blocks + 1, &ps)) return r;   // page-locked home of the block offsets
         s.ps = *ps;
         if (!s.rel_off.empty()) {                                           // chain already walked by the caller
             memcpy(s.ps.h_len, s.rel_off.data(), s.num_blocks * sizeof(uint64_t));
@@ -1502,7 +1529,7 @@ snappy_status decompress_pipelined(const uint8_t* buf, uint64_t in_total, struct
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         DecompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
+        HIP_TRY(hipSetDevice(devs.device_of(g)));
         if (!s.num_blocks) return 0;
         const size_t n = s.chunks.size();
         const uint64_t* rel = s.ps.h_len;
@@ -1562,7 +1589,7 @@ snappy_status decompress_pipelined(const uint8_t* buf, uint64_t in_total, struct
     t0 = now_seconds();
     rc = for_each_device(gpus, [&](int g) -> int {
         DecompressShard& s = sh[g];
-        HIP_TRY(set_shard_device(g));
+        HIP_TRY(hipSetDevice(devs.device_of(g)));
         s.release();
         return 0;
     });
@@ -1585,6 +1612,8 @@ snappy_status decompress_pipelined(const uint8_t* buf, uint64_t in_total, struct
 
 }  // namespace
 
+extern "C" {
+
 static snappy_status compress_gpu_body(struct host_buffer_context* input, struct host_buffer_context* output, uint32_t block_size,
                                        struct program_runtime* runtime)
 {
@@ -1602,7 +1631,8 @@ static snappy_status compress_gpu_body(struct host_buffer_context* input, struct
     }
     const uint64_t n = input->length;
     const uint64_t nb = snappy_hip_num_blocks(n, block_size);
-    int gpus = requested_gpus();
+    const ShardDevices devs = requested_devices();
+    int gpus = devs.shards;
     if (gpus <= 0) {
         fprintf(stderr, "snappy_hip: no HIP device available; the -d path has no CPU fallback\n");
         return SNAPPY_INVALID_INPUT;
@@ -1612,7 +1642,7 @@ static snappy_status compress_gpu_body(struct host_buffer_context* input, struct
     // partition: contiguous block ranges per device (snappy_compress.c:494-520)
     const uint64_t per = nb ? (nb + gpus - 1) / gpus : 0;
     std::vector<CompressShard> sh(gpus);
-    CompressCleanup cleanup{sh};
+    CompressCleanup cleanup{sh, devs};
     for (int g = 0; g < gpus; ++g) {
         sh[g].first_block = (uint64_t)g * per;
         const uint64_t last = std::min(nb, sh[g].first_block + per);
@@ -1628,7 +1658,7 @@ static snappy_status compress_gpu_body(struct host_buffer_context* input, struct
     // is the strictly phased copy-in / run / copy-out of the reference (snappy_compress.c:547-704).
     uint64_t chunk_blocks = pipeline_chunk_blocks(per, block_size);
     if (!chunk_blocks || per <= chunk_blocks) chunk_blocks = std::max<uint64_t>(per, 1);
-    return compress_pipelined(input, output, block_size, runtime, sh, gpus, hdr, hdr_len, stride, chunk_blocks);
+    return compress_pipelined(input, output, block_size, runtime, sh, gpus, devs, hdr, hdr_len, stride, chunk_blocks);
 }
 
 static snappy_status decompress_gpu_body(struct host_buffer_context* input, struct host_buffer_context* output,
@@ -1672,7 +1702,8 @@ static snappy_status decompress_gpu_body(struct host_buffer_context* input, stru
                 (unsigned long)((in_total - at) / 4));
         return SNAPPY_INVALID_INPUT;
     }
-    int gpus = requested_gpus();
+    const ShardDevices devs = requested_devices();
+    int gpus = devs.shards;
     if (gpus <= 0) {
         fprintf(stderr, "snappy_hip: no HIP device available; the -d path has no CPU fallback\n");
         return SNAPPY_INVALID_INPUT;
@@ -1685,13 +1716,13 @@ static snappy_status decompress_gpu_body(struct host_buffer_context* input, stru
     if (overlapped && gpus == 1) {
         // one shard: the host walks the size chain chunk by chunk inside the pipeline instead of up front
         std::vector<DecompressShard> one(1);
-        DecompressCleanup cleanup{one};
+        DecompressCleanup cleanup{one, devs};
         one[0].num_blocks = nb;
         one[0].in_off = one[0].walk_at = at;
         one[0].in_len = in_total - at;
         one[0].out_len = total;
         runtime->pre += now_seconds() - t0;
-        return decompress_pipelined(buf, in_total, output, runtime, one, 1, bs, total, chunk_blocks);
+        return decompress_pipelined(buf, in_total, output, runtime, one, 1, devs, bs, total, chunk_blocks);
     }
     // host pre-scan of the size chain (:306-341)
     std::vector<uint64_t> off(nb + 1);
@@ -1710,7 +1741,7 @@ static snappy_status decompress_gpu_body(struct host_buffer_context* input, stru
     }
     const uint64_t per = (nb + gpus - 1) / gpus;
     std::vector<DecompressShard> sh(gpus);
-    DecompressCleanup cleanup{sh};
+    DecompressCleanup cleanup{sh, devs};
     for (int g = 0; g < gpus; ++g) {
         DecompressShard& s = sh[g];
         s.first_block = (uint64_t)g * per;
@@ -1726,7 +1757,7 @@ static snappy_status decompress_gpu_body(struct host_buffer_context* input, stru
     }
     runtime->pre += now_seconds() - t0;
     // one chunk per shard = the strictly phased form (the size chain was walked above, in `pre`)
-    return decompress_pipelined(buf, in_total, output, runtime, sh, gpus, bs, total, overlapped ? chunk_blocks : std::max<uint64_t>(per, 1));
+    return decompress_pipelined(buf, in_total, output, runtime, sh, gpus, devs, bs, total, overlapped ? chunk_blocks : std::max<uint64_t>(per, 1));
 }
 
 // The exported pair: one call at a time per process (the cached pipeline streams and their page-locked scratch are per

@@ -364,11 +364,11 @@ int emu_decompress_variant(const uint8_t* stream, uint64_t stream_len, uint32_t 
     kb.status[0] = status.data();
     emu::launch(nb < 3 ? nb : 3, 64, [&] {
         if (variant == 0)
-            snappy_hip::decompress_blocks_kernel<true>(kb, block_size, &k2_counter);
+            snappy_hip::decompress_blocks_element_kernel<true>(kb, block_size, &k2_counter);
         else if (variant == 3)
-            snappy_hip::decompress_blocks_kernel<false, true>(kb, block_size, &k2_counter);      // per-window batch
+            snappy_hip::decompress_blocks_kernel(kb, block_size, &k2_counter);      // per-window batch
         else
-            snappy_hip::decompress_blocks_kernel<false>(kb, block_size, &k2_counter);
+            snappy_hip::decompress_blocks_element_kernel<false>(kb, block_size, &k2_counter);
     });
     for (uint32_t i = 0; i < nb; ++i)
         if (status[i] != 0) return 1;

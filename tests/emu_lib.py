@@ -15,7 +15,7 @@ def build():
     out = os.path.join(HERE, "emu", "libsnappy_emu.so")
     csrc = os.path.join(ROOT, "pim-compression_amd", "csrc")
     deps = [src, os.path.join(HERE, "emu", "hip", "hip_runtime.h"), os.path.join(csrc, "snappy_kernels.hpp"),
-            os.path.join(csrc, "snappy_k1_pair.hpp"), os.path.join(csrc, "snappy_k1_stream.hpp")] + [os.path.join(csrc, "ablation", f) for f in os.listdir(os.path.join(csrc, "ablation"))]
+            os.path.join(csrc, "snappy_k1_stream.hpp")] + [os.path.join(csrc, "ablation", f) for f in os.listdir(os.path.join(csrc, "ablation"))]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         # -DSNAPPY_ABLATION: the emulator also compiles the non-default kernel forms under csrc/ablation/
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DSNAPPY_ABLATION", "-I" + os.path.join(HERE, "emu"),

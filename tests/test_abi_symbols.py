@@ -14,7 +14,7 @@ def _declared_functions():
     with open(os.path.join(ROOT, "include", "snappy_hip.h")) as f:
         text = f.read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"\b(snappy_[a-z_]+)\s*\(", text)
+    names = re.findall(r"\b(snappy_[a-z0-9_]+)\s*\(", text)
     return sorted(set(names))
 
 
@@ -25,6 +25,25 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert "snappy_compress_gpu" in names and "snappy_decompress_gpu" in names and len(names) >= 14
     for n in names:
         assert hasattr(L, n), n
+
+
+def test_library_exports_nothing_but_the_declared_c_symbols():
+    """The drop-in library is linked into somebody else's C program: its unmangled dynamic symbols must be
+    exactly the functions include/snappy_hip.h declares -- no helper of the implementation (`report`, `walk_chain`, ...)
+    that a host program's own function of the same name could interpose.  (Built with -fvisibility=hidden; what remains
+    beside them are the mangled kernel handles of namespace snappy_hip and weak libstdc++ instantiations.)"""
+    import subprocess
+    path = entry.build_hip()
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    exported = [line.split() for line in out.splitlines() if line.strip()]
+    c_names = sorted(parts[-1] for parts in exported if not parts[-1].startswith("_"))
+    assert c_names == _declared_functions(), sorted(set(c_names) ^ set(_declared_functions()))
+    text_syms = [parts[-1] for parts in exported if parts[-2] in ("T", "t")]
+    assert sorted(text_syms) == _declared_functions(), text_syms
+    for parts in exported:                       # everything else is C++-mangled (kernel handles, std:: templates) or the HIP unit id
+        name = parts[-1]
+        assert name in c_names or name.startswith("_ZN10snappy_hip") or name.startswith("_ZNSt") or name.startswith("_ZSt") \
+            or name.startswith("__hip_"), name
 
 
 def test_code_object_targets_gfx950():
@@ -80,12 +99,13 @@ def test_k2_back_references_use_global_not_flat_instructions(tmp_path):
     asm = tmp_path / "device.s"
     subprocess.check_call([entry.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", str(asm)])
     text = asm.read_text()
-    m = re.search(r"^(_ZN10snappy_hip24decompress_blocks_kernelILb0ELb1EE\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
-    assert m, "decompress_blocks_kernel<false, true> (the per-window batch decoder) not found in the device code"
+    m = re.search(r"^(_ZN10snappy_hip24decompress_blocks_kernelE\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M)
+    assert m, "decompress_blocks_kernel (the per-window batch decoder) not found in the device code"
     body = m.group(2)
     assert len(re.findall(r"^\s*global_(?:load|store)", body, re.M)) >= 20
     assert re.findall(r"^\s*flat_\w+", body, re.M) == []
     # and the product library carries exactly one K1 pair, the two-wavefront form, and one K2 (no ablation instantiations)
     kernels = set(re.findall(r"^\s*\.amdhsa_kernel (\S+)", text, re.M))
     k1 = sorted(k for k in kernels if "_blocks_" in k and "decompress" not in k)
-    assert len(k1) == 3 and len([k for k in kernels if "decompress_blocks_kernel" in k]) == 1, sorted(kernels)
+    assert len([k for k in kernels if "decompress_blocks_kernel" in k]) == 1, sorted(kernels)
+    assert 2 <= len(k1) <= 4, k1     # the LDS-table and the global-table kernel, each in the bulk and / or the stream form

@@ -46,8 +46,12 @@ def test_bench_json_line_keeps_the_contract():
 
 
 def test_bench_two_ranks_on_one_device():
+    import socket
+    with socket.socket() as sock:                                 # a free port (a lingering run would hold a fixed one)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-              "--master-port", "29531", "bench.py", "--gpus", "2", "--containers", "2", "--container-mib", "64", "--steps", "2",
+              "--master-port", str(port), "bench.py", "--gpus", "2", "--containers", "2", "--container-mib", "64", "--steps", "2",
               "--warmup", "1", "--no-cpu-baseline"],
              env={"SNAPPY_BENCH_BACKEND": "gloo", "SNAPPY_BENCH_SINGLE_DEVICE": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0

@@ -143,3 +143,49 @@ def _datapath_worker(rank, world, port, q):
 def test_two_ranks_compress_their_shards_and_rank0_concatenates():
     got = _run(_datapath_worker)
     assert sum(c for _, c in got) == 10                     # every block of the file was compressed by exactly one rank
+
+
+def test_shard_to_device_mapping_and_stream_cache_key(tmp_path):
+    """csrc/shard_devices.hpp (the drop-in pair's per-call device map), compiled on the CPU: shard 0 runs on the caller's
+    current device, shard g on (base + g) % devices, and the cached stream sets are keyed by (device, shard) -- so a second
+    call entered with another current device never picks up streams created on the first call's device, and two shards that
+    share a device (oversubscription) never share a set."""
+    import subprocess
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <set>
+#include "shard_devices.hpp"
+int main() {
+    for (int physical = 1; physical <= 8; ++physical)
+        for (int base = 0; base < physical; ++base) {
+            ShardDevices d;
+            d.physical = physical;
+            d.base = base;
+            if (d.device_of(0) != base) return 1;                       // shard 0 on the caller's device
+            std::set<int> devs, keys;
+            for (int g = 0; g < physical; ++g) {
+                const int dev = d.device_of(g);
+                if (dev < 0 || dev >= physical || dev != (base + g) % physical) return 2;
+                devs.insert(dev);
+            }
+            if ((int)devs.size() != physical) return 3;                   // `physical` shards cover every device once
+            for (int g = 0; g < 64; ++g) keys.insert(pipeline_stream_key(d.device_of(g), g));
+            if (keys.size() != 64) return 4;                              // oversubscribed shards never share a stream set
+        }
+    // the same shard number on two different devices (two calls with different current devices) -> different sets
+    ShardDevices a, b;
+    a.physical = b.physical = 8;
+    a.base = 0;
+    b.base = 1;
+    for (int g = 0; g < 8; ++g)
+        if (pipeline_stream_key(a.device_of(g), g) == pipeline_stream_key(b.device_of(g), g)) return 5;
+    std::puts("ok");
+    return 0;
+}
+''')
+    exe = tmp_path / "t"
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pim-compression_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-I", csrc, str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.returncode

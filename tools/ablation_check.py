@@ -39,6 +39,9 @@ VARIANTS = [
     # K2: output window in LDS, both forms concurrently
     {"SNAPPY_HIP_DECOMPRESS_VARIANT": "0"}, {"SNAPPY_HIP_DECOMPRESS_VARIANT": "2", "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"},
     {"SNAPPY_HIP_K2_BATCH": "0"},
+    # round 2's two-wavefront LDS-table workgroups (csrc/ablation/k1_pair_kernel.hpp): alone, beside global-table wavefronts
+    {"SNAPPY_HIP_PAIR_PER_CU": "4", "SNAPPY_HIP_GT_WAVES": "0"}, {"SNAPPY_HIP_PAIR_PER_CU": "3"},
+    {"SNAPPY_HIP_PAIR_PER_CU": "1", "SNAPPY_HIP_GT_WAVES": "64"},
 ]
 
 
