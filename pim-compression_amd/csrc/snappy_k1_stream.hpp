@@ -72,7 +72,10 @@ constexpr uint32_t kStreamRoom = 192;   // the stream form takes a window when b
                                         // probed (:342), has 32 bytes to load, and no copy of < 64 bytes reaches the limit
 // slots per table of analyse() (two tables of dwords): 4 KiB of LDS beside the 32 KiB hash table, 2 KiB beside the 2 KiB
 // slot filter of a global-table wavefront
-constexpr uint32_t kStreamSlotsLds = 512, kStreamSlotsGlobal = 256;
+#ifndef SNAPPY_STREAM_SLOTS_LDS
+#define SNAPPY_STREAM_SLOTS_LDS 512
+#endif
+constexpr uint32_t kStreamSlotsLds = SNAPPY_STREAM_SLOTS_LDS, kStreamSlotsGlobal = 256;
 __host__ __device__ constexpr uint32_t stream_scratch_bytes(uint32_t slots) { return 8u * slots; }
 
 // unaligned 16-byte load (gfx950 runs with unaligned VMEM access enabled: one global_load_dwordx4)
@@ -106,11 +109,15 @@ __device__ __forceinline__ void stream_hash_window(StreamWindow& w, uint32_t shi
     w.e0 = (prod << (32 - shift)) & 0xffff0000u;
 }
 
+// index of the lowest set bit (0..31); all ones when x == 0 (v_ffbl_b32's own convention)
+__device__ __forceinline__ uint32_t first_bit(uint32_t x) { return (uint32_t)__builtin_ffs((int)x) - 1u; }
+__device__ __forceinline__ uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
 // the speculative gather of one window: table slot of every lane, 28 candidate bytes where the tag allows a hit
 struct StreamGather {
     uint32_t ent;
     uint4 ka, kb;
-    bool worth;
+    unsigned long long worthm;      // lanes whose candidate bytes were loaded (the tag allows a hit)
 };
 template <class Table>
 __device__ __forceinline__ void stream_issue_gather(StreamGather& g, const Table& table, const StreamWindow& w,
@@ -118,9 +125,10 @@ __device__ __forceinline__ void stream_issue_gather(StreamGather& g, const Table
 {
     const uint32_t mine_l = w.e0 | (w.base + lane);
     g.ent = table.load_lane(w.h0, mine_l);
-    g.worth = !Table::certain_miss(g.ent, mine_l);
+    const bool worth = !Table::certain_miss(g.ent, mine_l);
+    g.worthm = __ballot(worth);
     g.ka = g.kb = make_uint4(0, 0, 0, 0);
-    if (g.worth) {                                               // candidate <= position, and position + 32 <= block length
+    if (worth) {                                               // candidate <= position, and position + 32 <= block length
         const uint8_t* __restrict__ c = blk + (g.ent & 0xffffu);
         g.ka = ld128(c);
         g.kb = ld128(c + 16);
@@ -151,7 +159,7 @@ __device__ __forceinline__ uint32_t lds_max_rtn(lds_words_t p, uint32_t v)
 #endif
 
 struct StreamDup {
-    uint32_t j1 = 64;                   // per lane: nearest earlier lane with the same hash (64 = none)
+    uint32_t j1 = 0;                    // per lane of nf: nearest earlier lane with the same hash
     uint32_t extj = 0;                  // per lane with a partner: bytes of the 8 behind the key that match the partner's (0..8)
     unsigned long long nf = 0;          // lanes that have a partner
     unsigned long long hitj = 0;        // of those: the 4-byte keys are equal (a probe hits if the partner is the slot's content)
@@ -201,19 +209,21 @@ __device__ __forceinline__ void stream_analyse(StreamDup& d, const StreamWindow&
     }
     const uint32_t ha = (uint32_t)__shfl((int)w.h0, (int)(ja & 63u));
     const uint32_t hb = (uint32_t)__shfl((int)w.h0, (int)(jb & 63u));
-    const bool ma = oa && ha == w.h0, mb = ob && hb == w.h0;
-    const bool has = ma || mb;
-    d.j1 = ma ? ja : (mb ? jb : 64u);
-    d.nf = __ballot(has);
-    d.cx = __ballot(!has && oa && ob);
+    const unsigned long long OA = __ballot(oa != 0), OB = __ballot(ob != 0);
+    const unsigned long long MA = OA & __ballot(ha == w.h0), MB = OB & __ballot(hb == w.h0);
+    const bool ma = __builtin_amdgcn_inverse_ballot_w64(MA);
+    d.j1 = ma ? ja : jb;                                         // (meaningful in the lanes of nf)
+    d.nf = MA | MB;
+    d.cx = OA & OB & ~d.nf;
     if (d.nf) {
         const uint32_t jl = d.j1 & 63u;
         const uint32_t xj = (uint32_t)__shfl((int)w.a.x, (int)jl);
         const uint32_t e1 = (uint32_t)__shfl((int)w.a.y, (int)jl) ^ w.a.y;
         const uint32_t e2 = (uint32_t)__shfl((int)w.a.z, (int)jl) ^ w.a.z;
-        d.hitj = __ballot(has && xj == w.a.x);
-        d.extj = e1 ? ((uint32_t)__builtin_ctz(e1) >> 3) : (e2 ? 4u + ((uint32_t)__builtin_ctz(e2) >> 3) : 8u);
-        d.deep = __ballot(has && (((d.nf | d.cx) >> jl) & 1ull));
+        d.hitj = d.nf & __ballot(xj == w.a.x);
+        d.extj = min_u32(min_u32(first_bit(e1), first_bit(e2) | 32u), 64u) >> 3;
+        const unsigned long long chained = d.nf | d.cx;
+        d.deep = d.nf & __ballot(((uint32_t)(chained >> jl) & 1u) != 0);
     }
 }
 
@@ -221,7 +231,7 @@ __device__ __forceinline__ void stream_analyse(StreamDup& d, const StreamWindow&
 // window; s_bitset1_b64 / v_readlane_b32 / s_bfm_b64 only look at the low six bits of their index, which t and the lane
 // share.  advv = per lane: copy length for a hit, distance to the next HIT-or-stop lane for a miss, 64 for a stop lane;
 // clv = copy length for a hit, else 0.  V collects the lanes visited, COV the lanes covered by the copies taken.
-// On gfx950 this is 7 instructions per visited lane; the C++ body is the same algorithm for the CPU emulator.
+// On gfx950 this is 7 instructions per visited lane (four lanes per trip of the loop); the C++ body is the same algorithm for the CPU emulator.
 __device__ __forceinline__ void stream_walk(uint32_t advv, uint32_t clv, uint32_t& t, unsigned long long& V, unsigned long long& COV)
 {
 #ifdef SNAPPY_EMU
@@ -239,7 +249,7 @@ __device__ __forceinline__ void stream_walk(uint32_t advv, uint32_t clv, uint32_
 #else
     uint32_t a, c;
     unsigned long long m;
-    asm volatile(
+    asm volatile(                                // four lanes per trip: a branch that falls through is cheaper than one taken
         "1:\n"
         "  s_bitset1_b64 %[V], %[t]\n"
         "  v_readlane_b32 %[a], %[advv], %[t]\n"
@@ -251,7 +261,21 @@ __device__ __forceinline__ void stream_walk(uint32_t advv, uint32_t clv, uint32_
         "  s_bitset1_b64 %[V], %[t]\n"
         "  v_readlane_b32 %[a], %[advv], %[t]\n"
         "  v_readlane_b32 %[c], %[clv], %[t]\n"
-        "  s_bfm_b64 %[m], %[c], %[t]\n"
+        "  s_bfm_b64 %[m], %[c], %[t]\n"        // ((1 << c) - 1) << t
+        "  s_or_b64 %[COV], %[COV], %[m]\n"
+        "  s_add_u32 %[t], %[t], %[a]\n"
+        "  s_cbranch_scc1 2f\n"
+        "  s_bitset1_b64 %[V], %[t]\n"
+        "  v_readlane_b32 %[a], %[advv], %[t]\n"
+        "  v_readlane_b32 %[c], %[clv], %[t]\n"
+        "  s_bfm_b64 %[m], %[c], %[t]\n"        // ((1 << c) - 1) << t
+        "  s_or_b64 %[COV], %[COV], %[m]\n"
+        "  s_add_u32 %[t], %[t], %[a]\n"
+        "  s_cbranch_scc1 2f\n"
+        "  s_bitset1_b64 %[V], %[t]\n"
+        "  v_readlane_b32 %[a], %[advv], %[t]\n"
+        "  v_readlane_b32 %[c], %[clv], %[t]\n"
+        "  s_bfm_b64 %[m], %[c], %[t]\n"        // ((1 << c) - 1) << t
         "  s_or_b64 %[COV], %[COV], %[m]\n"
         "  s_add_u32 %[t], %[t], %[a]\n"
         "  s_cbranch_scc0 1b\n"
@@ -270,6 +294,14 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
 #else
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) { return v; }
 #endif
+
+// what a copy that lands on lane `land` adds to its advance: the distance from there to the next lane where something
+// happens, when the landing lane itself is a plain miss inside the window (see finalize)
+__device__ __forceinline__ uint32_t stream_past(uint32_t dist, unsigned long long inter, uint32_t land)
+{
+    if (land >= kWave || ((inter >> land) & 1ull)) return 0;
+    return (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)land);
+}
 
 // m has a run of 34 or more consecutive set bits
 __device__ __forceinline__ bool has_run_of_34(unsigned long long m)
@@ -323,29 +355,45 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
             PROF_LAP(1);                                         // 1: waiting for the candidate loads (probe builds only: all of them)
 
             // ---------------- finalize(W): what a probe at each lane would find ----------------
-            const bool hitl = g.worth && g.ka.x == cur.a.x;
-            const uint32_t d1 = g.ka.y ^ cur.a.y, d2 = g.ka.z ^ cur.a.z, d3 = g.ka.w ^ cur.a.w, d4 = g.kb.x ^ cur.b.x, d5 = g.kb.y ^ cur.b.y,
-                           d6 = g.kb.z ^ cur.b.z;
-            uint32_t extv = d1 ? ((uint32_t)__builtin_ctz(d1) >> 3)
-                               : (d2 ? 4u + ((uint32_t)__builtin_ctz(d2) >> 3)
-                                     : (d3 ? 8u + ((uint32_t)__builtin_ctz(d3) >> 3)
-                                           : (d4 ? 12u + ((uint32_t)__builtin_ctz(d4) >> 3)
-                                                 : (d5 ? 16u + ((uint32_t)__builtin_ctz(d5) >> 3)
-                                                       : (d6 ? 20u + ((uint32_t)__builtin_ctz(d6) >> 3) : 24u)))));
+            unsigned long long hitm = __ballot(g.ka.x == cur.a.x) & g.worthm;
+            // bytes of the 24 behind the key that match the candidate's: first differing bit of the 192, found without a branch
+            // (first_bit: 0..31, or all ones for a zero word, which the ORs keep as "none" and the minimum ignores)
+            const uint32_t t1 = min_u32(first_bit(g.ka.y ^ cur.a.y), first_bit(g.ka.z ^ cur.a.z) | 32u);
+            const uint32_t t2 = min_u32(first_bit(g.ka.w ^ cur.a.w), first_bit(g.kb.x ^ cur.b.x) | 32u) | 64u;
+            const uint32_t t3 = min_u32(first_bit(g.kb.y ^ cur.b.y), first_bit(g.kb.z ^ cur.b.z) | 32u) | 128u;
+            uint32_t extv = min_u32(min_u32(t1, t2), min_u32(t3, 192u)) >> 3;
             uint32_t ent = g.ent & 0xffffu;
-            unsigned long long hitm = __ballot(hitl);
             // stop lanes: the partner lies at or above the cursor (below it, nothing was inserted there since the gather: the
             // gathered entry stands), hidden partners, and hits whose compared bytes all match
-            const unsigned long long pend = __ballot(dup.j1 < 64u && dup.j1 >= r0);
-            unsigned long long stopm = pend | dup.cx | __ballot(hitl && extv == 24u);
+            const unsigned long long pend = dup.nf & __ballot(dup.j1 >= r0);
+            const unsigned long long satm = hitm & __ballot(extv == 24u);
+            unsigned long long stopm = pend | dup.cx | satm;
             const unsigned long long above_r0 = ~0ull << r0;
             // jump vector: the next lane above this one where something happens (HIT or stop), else the window's end
             const unsigned long long inter = hitm | stopm;
             const unsigned long long up = (lane < 63u) ? (inter >> (lane + 1u)) : 0ull;
             const uint32_t dist = up ? (uint32_t)__builtin_ctzll(up) + 1u : 64u - lane;
             const bool stopl = __builtin_amdgcn_inverse_ballot_w64(stopm);
-            uint32_t clv = (hitl && !stopl) ? 4u + extv : 0u;
-            uint32_t advv = stopl ? 64u : (hitl ? 4u + extv : dist);
+            const bool hitl = __builtin_amdgcn_inverse_ballot_w64(hitm);
+            // what the lane does if the gathered entry stands (advt / clt) and if its partner is the slot's content (advj / clj);
+            // a stop lane carries 64 / 0 until it is settled with one of the two
+            // A copy that lands on a lane where nothing happens goes straight on to the next lane where something does: the
+            // landing lane is a plain miss (a scan probe, :336-348) and needs no step of its own.  `past` = what to add to a
+            // copy of the given length from this lane: the landing lane's own distance, 0 when the landing lane is a hit or
+            // a stop (or beyond the window)
+            const uint32_t clt = hitl ? 4u + extv : 0u;
+            const bool hitjl = __builtin_amdgcn_inverse_ballot_w64(dup.hitj);
+            const uint32_t clj = hitjl ? 4u + dup.extj : 0u;
+            const uint32_t land_t = lane + clt, land_j = lane + clj;
+            const uint32_t dist_t = (uint32_t)__shfl((int)dist, (int)(land_t & 63u));
+            const uint32_t dist_j = (uint32_t)__shfl((int)dist, (int)(land_j & 63u));
+            const bool plain_t = land_t < 64u && !((inter >> (land_t & 63u)) & 1ull);
+            const bool plain_j = land_j < 64u && !((inter >> (land_j & 63u)) & 1ull);
+            const uint32_t advt = hitl ? clt + (plain_t ? dist_t : 0u) : dist;
+            const uint32_t advj = hitjl ? clj + (plain_j ? dist_j : 0u) : dist;
+            const unsigned long long satjm = dup.hitj & __ballot(dup.extj == 8u);
+            uint32_t clv = stopl ? 0u : clt;
+            uint32_t advv = stopl ? 64u : advt;
             PROF_LAP(2);                                         // 2: finalize
 
             // ---------------- walk(W) ----------------
@@ -358,8 +406,6 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
                 // (the structurizer turns these loop-carried scalars into vector PHIs around the settle's branches; read them
                 // back before the walk's inline assembly, which takes them in SGPRs)
                 t = uni(t);
-                V = uni64(V);
-                COV = uni64(COV);
                 stream_walk(advv, clv, t, V, COV);
                 const uint32_t s = 63u - (uint32_t)__builtin_clzll(V);   // the lane visited last
                 if (!((stopm >> s) & 1ull)) {                    // left the window: behind a copy, or by a miss at lane 63
@@ -369,21 +415,24 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
                 PROF_LAP(3);                                     // 3: walk proper
                 // ---- the walk stands on a stop lane: settle that one probe ----
                 STREAM_STAT(3);
-                const unsigned long long below_s = (1ull << s) - 1ull;
+                const unsigned long long bit_s = 1ull << s;
+                const unsigned long long below_s = bit_s - 1ull;
                 const unsigned long long interior_s = COV & ~(V & hitm & below_s);
                 uint32_t how = 0;                                // 0: the gathered entry stands, 1: the partner lane, 2: ask the ballot
                 uint32_t j = 0;
-                if ((pend >> s) & 1ull) {
+                if (pend & bit_s) {
                     // the slot holds the partner if it was inserted since the gather: probed, or the last lane of a copy --
                     // i.e. NOT a covered lane whose successor is covered too
                     j = (uint32_t)__builtin_amdgcn_readlane((int)dup.j1, (int)s);
                     const unsigned long long not_inserted = interior_s & (interior_s >> 1);
                     if (!((not_inserted >> j) & 1ull)) how = 1;
-                    else if ((dup.deep >> s) & 1ull) how = 2;    // a further lane of the chain may have been
+                    else if (dup.deep & bit_s) how = 2;          // a further lane of the chain may have been
                 }
-                if ((dup.cx >> s) & 1ull) how = 2;
-                bool hit_s = false;
-                uint32_t cand_s = 0, ext_s = 0, sat_s = 24;
+                if (dup.cx & bit_s) how = 2;
+                // what the lane does: (advance, copy length) for the walk, (candidate, length - 4) for the emission, and
+                // whether the compared bytes all matched (the match may run on)
+                uint32_t adv_s, cl_s, cand_s = 0, sat_s = 24;
+                bool hit_s, more_s;
                 if (how == 2) {
                     // the long way: the latest inserted lane with this hash, by ballot (as the bulk form does for every sharer)
                     STREAM_STAT(6);
@@ -393,57 +442,56 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
                     how = 0;
                     if (J) {
                         j = 63u - (uint32_t)__builtin_clzll(J);
-                        cand_s = cur.base + j;
                         hit_s = (uint32_t)__builtin_amdgcn_readlane((int)cur.a.x, (int)s) == (uint32_t)__builtin_amdgcn_readlane((int)cur.a.x, (int)j);
                         const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)cur.a.y, (int)s) ^ (uint32_t)__builtin_amdgcn_readlane((int)cur.a.y, (int)j);
                         const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)cur.a.z, (int)s) ^ (uint32_t)__builtin_amdgcn_readlane((int)cur.a.z, (int)j);
-                        ext_s = e1 ? ((uint32_t)__builtin_ctz(e1) >> 3) : (e2 ? 4u + ((uint32_t)__builtin_ctz(e2) >> 3) : 8u);
+                        const uint32_t ext_s = e1 ? ((uint32_t)__builtin_ctz(e1) >> 3) : (e2 ? 4u + ((uint32_t)__builtin_ctz(e2) >> 3) : 8u);
+                        cand_s = cur.base + j;
                         sat_s = 8;
+                        more_s = hit_s && ext_s == 8u;
+                        cl_s = hit_s ? 4u + ext_s : 0u;
+                        adv_s = hit_s ? cl_s : (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)s);
+                        if (hit_s && !more_s) adv_s += stream_past(dist, hitm | stopm, s + cl_s);
                         how = 3;
                     }
                 }
-                if (how == 1) {
+                if (how == 1) {                                  // both results were computed for all lanes at once
                     STREAM_STAT(9);
+                    hit_s = (dup.hitj & bit_s) != 0;
+                    more_s = (satjm & bit_s) != 0;
+                    adv_s = (uint32_t)__builtin_amdgcn_readlane((int)advj, (int)s);
+                    cl_s = (uint32_t)__builtin_amdgcn_readlane((int)clj, (int)s);
                     cand_s = cur.base + j;
-                    hit_s = (dup.hitj >> s) & 1ull;
-                    ext_s = (uint32_t)__builtin_amdgcn_readlane((int)dup.extj, (int)s);
                     sat_s = 8;
                 } else if (how == 0) {
                     STREAM_STAT(10);
-                    hit_s = (hitm >> s) & 1ull;
-                    cand_s = (uint32_t)__builtin_amdgcn_readlane((int)ent, (int)s);
-                    ext_s = (uint32_t)__builtin_amdgcn_readlane((int)extv, (int)s);
-                    sat_s = 24;
+                    hit_s = (hitm & bit_s) != 0;
+                    more_s = (satm & bit_s) != 0;
+                    adv_s = (uint32_t)__builtin_amdgcn_readlane((int)advt, (int)s);
+                    cl_s = (uint32_t)__builtin_amdgcn_readlane((int)clt, (int)s);
                 }
-                uint32_t len_s = 4u + ext_s;
-                if (hit_s && ext_s == sat_s) {
+                if (more_s) {
                     STREAM_STAT(8);
-                    len_s = 4u + sat_s + match_extend(blk, cand_s + 4u + sat_s, cur.base + s + 4u + sat_s, n, lane);
+                    if (how == 0) cand_s = (uint32_t)__builtin_amdgcn_readlane((int)ent, (int)s);
+                    cl_s = 4u + sat_s + match_extend(blk, cand_s + 4u + sat_s, cur.base + s + 4u + sat_s, n, lane);
+                    adv_s = cl_s <= 63u ? cl_s + stream_past(dist, hitm | stopm, s + cl_s) : cl_s;
+                    if (cl_s > 63u) {                            // more than one copy element (:254-272): taken behind this segment
+                        STREAM_STAT(2);
+                        V &= ~bit_s;
+                        r_out = s;
+                        long_copy = true;
+                        long_cand = cand_s;
+                        long_len = cl_s;
+                        break;
+                    }
                 }
-                if (hit_s && len_s > 63u) {                      // more than one copy element (:254-272): taken behind this segment
-                    STREAM_STAT(2);
-                    V &= ~(1ull << s);
-                    r_out = s;
-                    long_copy = true;
-                    long_cand = cand_s;
-                    long_len = len_s;
-                    break;
-                }
-                stopm &= ~(1ull << s);
-                uint32_t adv_s;
-                if (hit_s) {
-                    hitm |= 1ull << s;
-                    adv_s = len_s;
-                } else {
-                    hitm &= ~(1ull << s);
-                    const unsigned long long ups = (s < 63u) ? ((hitm | stopm) >> (s + 1u)) : 0ull;
-                    adv_s = ups ? (uint32_t)__builtin_ctzll(ups) + 1u : 64u - s;
-                }
+                stopm &= ~bit_s;
+                hitm = hit_s ? (hitm | bit_s) : (hitm & ~bit_s);
                 if (lane == s) {
-                    extv = len_s - 4u;
-                    ent = cand_s;
                     advv = adv_s;
-                    clv = hit_s ? len_s : 0u;
+                    clv = cl_s;
+                    if (how != 0) ent = cand_s;                  // (the gathered entry is there already)
+                    if (how != 0 || more_s) extv = cl_s - 4u;
                 }
                 t = s - 64u;
                 PROF_LAP(4);                                     // 4: settles
