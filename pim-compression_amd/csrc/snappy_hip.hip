@@ -113,7 +113,7 @@ constexpr int kDefaultK1FormLds = 2;    // bulk form for the LDS-table kernel
 constexpr int kDefaultLdsWaves = 768;   // block sizes above 8 KiB: 3 LDS-table wavefronts per CU (3 x 33 KiB) beside 20 global-table ones (3 KiB each: filter + duplicate test)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 constexpr uint32_t kCus = 256, kLdsPerCu = 160u << 10, kWaveSlotsPerCu = 32;
-constexpr int kDefaultK1Stream = 1;     // SNAPPY_HIP_K1_STREAM: bit 0 = stream form (snappy_k1_stream.hpp) for the LDS-table kernel (default: +2 % in the mix), bit 1 = for the global-table kernel (-2 %)
+constexpr int kDefaultK1Stream = 1;     // SNAPPY_HIP_K1_STREAM: bit 0 = stream form (snappy_k1_stream.hpp) for the LDS-table kernel (default: +2 % in the mix), bit 1 = for the global-table kernel (-2 %), (ablation build: bit 2 = duo form, two wavefronts per LDS-table block)
 constexpr int kDefaultPairPerCu = 0;    // two-wavefront LDS-table workgroups per CU beside the global-table wavefronts (0 = round 1's one-wavefront LDS-table kernel)
 
 // Work counters for persistent kernels: a ring in the code object's own global memory (one copy per device), so launches
@@ -407,9 +407,16 @@ void launch_lds_table_kernel(const K1Forms& f, uint32_t grid, hipStream_t st, co
                              uint32_t slot_stride, uint32_t* counter)
 {
 #ifdef SNAPPY_ABLATION
-    SNAPPY_K1_DISPATCH(launch_k1_lds, f.ahead_lds, f.form_lds, grid, f.extra_lds, st, w, block_size, slot_stride, counter);
+    if (env_int("SNAPPY_HIP_K1_STREAM", 0) & 4)                      // duo form (csrc/ablation/k1_duo_form.hpp): `grid` workgroups of two wavefronts
+        hipLaunchKernelGGL(snappy_hip::compress_blocks_duo_kernel, dim3(grid), dim3(128), snappy_hip::duo_lds_bytes(block_size), st, w,
+                           block_size, slot_stride, counter);
+    else if (env_int("SNAPPY_HIP_K1_STREAM", 0) & 1)
+        hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<64, 3>), dim3(grid), dim3(64),
+                           snappy_hip::lds_table_stream_lds_bytes(block_size), st, w, block_size, slot_stride, counter);
+    else
+        SNAPPY_K1_DISPATCH(launch_k1_lds, f.ahead_lds, f.form_lds, grid, f.extra_lds, st, w, block_size, slot_stride, counter);
 #else
-    if (env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream))
+    if (env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream) & 1)
         hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<64, 3>), dim3(grid), dim3(64),
                            snappy_hip::lds_table_stream_lds_bytes(block_size), st, w, block_size, slot_stride, counter);
     else
@@ -673,10 +680,19 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
     uint32_t waves;                                                                        // (decided BEFORE the wave budget below)
     {
         const uint32_t lds_per_cu = (lds_waves + kCus - 1) / kCus;
-        const uint32_t lds_wave_bytes = lds_alloc_bytes(((k1_stream & 1) ? snappy_hip::lds_table_stream_lds_bytes(block_size)
-                                                                         : snappy_hip::lds_table_kernel_lds_bytes(block_size, forms.form_lds != 0)) +
+#ifdef SNAPPY_ABLATION
+        const bool duo = (k1_stream & 4) != 0;
+        const uint32_t duo_bytes = snappy_hip::duo_lds_bytes(block_size);
+#else
+        const bool duo = false;
+        const uint32_t duo_bytes = 0;
+#endif
+        const uint32_t lds_wave_bytes = lds_alloc_bytes((duo ? duo_bytes
+                                                         : (k1_stream & 1) ? snappy_hip::lds_table_stream_lds_bytes(block_size)
+                                                                           : snappy_hip::lds_table_kernel_lds_bytes(block_size, forms.form_lds != 0)) +
                                                         forms.extra_lds);
-        uint32_t g_per_cu = kWaveSlotsPerCu > lds_per_cu ? kWaveSlotsPerCu - lds_per_cu : 0u;
+        const uint32_t lds_slots = lds_per_cu * (duo ? 2u : 1u);                    // a duo workgroup takes two wave slots
+        uint32_t g_per_cu = kWaveSlotsPerCu > lds_slots ? kWaveSlotsPerCu - lds_slots : 0u;
         if (g_wave_bytes && lds_per_cu * lds_wave_bytes < kLdsPerCu)
             g_per_cu = std::min(g_per_cu, (kLdsPerCu - lds_per_cu * lds_wave_bytes) / lds_alloc_bytes(g_wave_bytes));
         waves = lds_waves + g_per_cu * kCus;

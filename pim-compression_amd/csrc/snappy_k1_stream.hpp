@@ -322,18 +322,52 @@ __device__ __forceinline__ void stream_put(const Table& table, uint32_t x, uint3
     table.put(prod >> shift, ((prod << (32 - shift)) & 0xffff0000u) | pos, lane);
 }
 
+// What the stream form hands to "the other half" of a window's work -- the duplicate analysis in front of the parse and the
+// emission behind it.  One wavefront per block: both are done in place.  (snappy_k1_duo.hpp: a second wavefront does them.)
+__device__ __forceinline__ void stream_emit(uint8_t* __restrict__ dst, const uint8_t* __restrict__ blk, uint32_t& op, uint32_t& next_emit,
+                                            uint32_t base, uint32_t x0, uint32_t ent, uint32_t extv, unsigned long long H,
+                                            unsigned long long COV, bool by_copy, uint32_t r_out, bool long_copy, uint32_t ip,
+                                            uint32_t long_cand, uint32_t long_len, uint32_t lane)
+{
+    if (H) emit_segment(dst, blk, op, next_emit, base, x0, ent, extv, H, COV, by_copy, r_out, lane);
+    if (long_copy) {
+        if (ip > next_emit) op = emit_literal_windowed(dst, op, blk, next_emit, ip - next_emit, base, x0, lane);
+        op = emit_copy(dst, op, ip - long_cand, long_len, lane);
+        next_emit = ip + long_len;
+    }
+}
+
+struct SoloMate {
+    static constexpr bool kAnalysesInPlace = true;               // analyse()'s tables live in the caller's scratch
+    __device__ __forceinline__ void begin(uint32_t, uint32_t, uint32_t) {}
+    __device__ __forceinline__ void drain(uint32_t&, uint32_t&, uint32_t) {}
+    template <uint32_t kSlots>
+    __device__ __forceinline__ void analysis(StreamDup& d, const StreamWindow& w, lds_bytes_t scratch, uint32_t lane)
+    {
+        stream_analyse<kSlots>(d, w, scratch, lane);
+    }
+    __device__ __forceinline__ void emit(uint8_t* __restrict__ dst, const uint8_t* __restrict__ blk, uint32_t& op, uint32_t& next_emit,
+                                         uint32_t base, uint32_t x0, uint32_t ent, uint32_t extv, unsigned long long H,
+                                         unsigned long long COV, bool by_copy, uint32_t r_out, bool long_copy, uint32_t ip,
+                                         uint32_t long_cand, uint32_t long_len, uint32_t lane)
+    {
+        stream_emit(dst, blk, op, next_emit, base, x0, ent, extv, H, COV, by_copy, r_out, long_copy, ip, long_cand, long_len, lane);
+    }
+};
+
 // Stream form from `ps` on.  Precondition: stride 1 (ps.skip < 64) and the window of ps.ip is eligible
 // (base + kStreamRoom <= limit).  Takes windows until one is not eligible, a run of misses widens the stride, or the
 // scan is over behind a long copy; `ps` is then exactly the reference's state in front of the probe at ps.ip.  May
 // return without progress (first window sent back): the caller follows with bulk_run().
-template <class Table, uint32_t kSlots>
+template <class Table, uint32_t kSlots, class Mate>
 __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint32_t avail, uint32_t n, uint32_t shift,
                                            uint8_t* __restrict__ dst, const Table table, uint32_t lane, lds_bytes_t dup_scratch,
-                                           ParseState& ps, StreamProf& prof)
+                                           ParseState& ps, StreamProf& prof, Mate& mate)
 {
     const uint32_t limit = n - kInputMargin;
     const uint32_t last16 = avail - 16u;
     uint32_t ip = ps.ip, skip = ps.skip, op = ps.op, next_emit = ps.next_emit;
+    mate.begin(op, next_emit, lane);
 
     for (;;) {   // ---- (re)start of the pipeline at the window of ip ----
         StreamWindow cur, nxt;
@@ -344,7 +378,7 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
         __builtin_amdgcn_sched_barrier(0);
         stream_load_window(nxt, blk, cur.base + 64u, last16, lane);
         StreamDup dup;
-        stream_analyse<kSlots>(dup, cur, dup_scratch, lane);
+        mate.template analysis<kSlots>(dup, cur, dup_scratch, lane);
         PROF_LAP(0);                                             // 0: priming (first window's loads issued, analysed)
         bool restart = false;                                    // a long copy was taken: the pipeline restarts where it landed
 
@@ -572,15 +606,15 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
             PROF_LAP(6);                                         // 6: next window's table read and loads issued
 
             // ---------------- emit(W) ----------------
-            if (H) emit_segment(dst, blk, op, next_emit, old.base, old.a.x, old_ent, old_extv, H, COV, by_copy, r_out, lane);
+            // (the segment's elements, and behind them the copy of 64+ bytes at ip if there is one: the literal in front of it,
+            // :355, and its elements, :254-272)
+            if (H || long_copy)
+                mate.emit(dst, blk, op, next_emit, old.base, old.a.x, old_ent, old_extv, H, COV, by_copy, r_out, long_copy, ip, long_cand,
+                          long_len, lane);
             PROF_LAP(7);                                         // 7: emission
 
             if (long_copy) {
-                // the copy of 64+ bytes at ip: the literal in front of it (:355), its elements (:254-272), the cursor behind it
-                if (ip > next_emit) op = emit_literal_windowed(dst, op, blk, next_emit, ip - next_emit, old.base, old.a.x, lane);
-                op = emit_copy(dst, op, ip - long_cand, long_len, lane);
-                ip += long_len;
-                next_emit = ip;
+                ip += long_len;                                  // the cursor behind the copy
                 skip = 31;
                 if (ip < limit) {                                // :388-392
                     stream_put(table, uld32(blk + ip - 1u), ip - 1u, shift, lane);
@@ -595,11 +629,12 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
                 break;
             }
             // ---------------- analyse(W+1) ----------------
-            stream_analyse<kSlots>(dup, cur, dup_scratch, lane);
+            mate.template analysis<kSlots>(dup, cur, dup_scratch, lane);
             PROF_LAP(8);                                         // 8: duplicate-slot analysis
         }
         if (!restart) break;
     }
+    mate.drain(op, next_emit, lane);
     ps.ip = ip;
     ps.skip = skip;
     ps.op = op;
@@ -607,10 +642,10 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
 }
 
 // One block: the stream form for every window it takes, the bulk form for the rest.
-template <class Table, uint32_t kSlots>
+template <class Table, uint32_t kSlots, class Mate>
 __device__ __forceinline__ void compress_one_block_stream(const uint8_t* __restrict__ base16, uint64_t start, uint64_t in_len,
                                                           uint32_t n, uint8_t* __restrict__ dst, const Table table_in, uint32_t lane,
-                                                          uint32_t* __restrict__ block_bytes_out, lds_bytes_t dup_scratch)
+                                                          uint32_t* __restrict__ block_bytes_out, lds_bytes_t dup_scratch, Mate& mate)
 {
     const uint8_t* __restrict__ blk = base16 + start;
     const uint32_t ts = table_entries_for(n);                    // get_hash_table, :139-146 (+ shift, :288)
@@ -618,7 +653,8 @@ __device__ __forceinline__ void compress_one_block_stream(const uint8_t* __restr
     const uint32_t e_zero = (n >= kInputMargin) ? (((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u) : 0u;
     const Table table = table_in.with_empty(e_zero);
     if (n >= kInputMargin) table.init(ts, e_zero, lane);
-    for (uint32_t i = lane; i < 2u * kSlots; i += kWave) ((lds_words_t)dup_scratch)[i] = 0;   // analyse() keeps its tables zeroed
+    if (Mate::kAnalysesInPlace)
+        for (uint32_t i = lane; i < 2u * kSlots; i += kWave) ((lds_words_t)dup_scratch)[i] = 0;   // analyse() keeps its tables zeroed
     __builtin_amdgcn_wave_barrier();
     ParseState ps;
     StreamProf prof;
@@ -631,13 +667,14 @@ __device__ __forceinline__ void compress_one_block_stream(const uint8_t* __restr
             if (ps.skip < 64u && (ps.ip & ~63u) + kStreamRoom <= limit) {
                 STREAM_STAT(4);
                 PROF_LAP(12);                                    // 12: table clear, loop glue
-                stream_run<Table, kSlots>(blk, avail, n, shift, dst, table, lane, dup_scratch, ps, prof);
+                stream_run<Table, kSlots, Mate>(blk, avail, n, shift, dst, table, lane, dup_scratch, ps, prof, mate);
                 if (ps.ip >= limit) break;                       // the scan ended behind a long copy (:388-389)
             }
             STREAM_STAT(5);
             // at least one step of the bulk form, then on to the next window boundary at stride 1
             const bool over = bulk_run<Table, 64>(blk, avail, n, shift, dst, table, lane, dup_scratch, ps, (ps.ip | 63u) + 1u);
-            for (uint32_t i = lane; i < 2u * kSlots; i += kWave) ((lds_words_t)dup_scratch)[i] = 0;   // its race tables used the bytes
+            if (Mate::kAnalysesInPlace)
+                for (uint32_t i = lane; i < 2u * kSlots; i += kWave) ((lds_words_t)dup_scratch)[i] = 0;   // its race tables used the bytes
             __builtin_amdgcn_wave_barrier();
             PROF_LAP(11);                                        // 11: the bulk form
             if (over) break;

@@ -1112,8 +1112,11 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const K1B
         static_assert(kForm == 2 || kForm == 3, "the product ships the bulk and stream forms; other forms need -DSNAPPY_ABLATION");
 #endif
         if constexpr (kForm == 3)   // (launched with lds_table_stream_lds_bytes(block_size) of dynamic LDS)
+        {
+            SoloMate solo;
             compress_one_block_stream<LdsTable, kStreamSlotsLds>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out,
-                                                                 (lds_bytes_t)dup_scratch);
+                                                                 (lds_bytes_t)dup_scratch, solo);
+        }
         else
             compress_one_block_bulk<LdsTable, kAhead>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out,
                                                       (lds_bytes_t)dup_scratch);
@@ -1172,7 +1175,11 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
         else
 #endif
         if constexpr (kForm == 3)
-            compress_one_block_stream<Table, kStreamSlotsGlobal>(in, start, in_len, n, slot, table, lane, bytes_out, (lds_bytes_t)dup_scratch);
+        {
+            SoloMate solo;
+            compress_one_block_stream<Table, kStreamSlotsGlobal>(in, start, in_len, n, slot, table, lane, bytes_out, (lds_bytes_t)dup_scratch,
+                                                                 solo);
+        }
         else
             compress_one_block_bulk<Table, kAhead>(in, start, in_len, n, slot, table, lane, bytes_out, (lds_bytes_t)dup_scratch);
     }
@@ -1187,6 +1194,12 @@ namespace snappy_hip {
 #ifdef SNAPPY_ABLATION
 }  // namespace snappy_hip
 #include "ablation/k1_simt_kernels.hpp"
+namespace snappy_hip {
+#endif
+
+#ifdef SNAPPY_ABLATION
+}  // namespace snappy_hip
+#include "ablation/k1_duo_form.hpp"
 namespace snappy_hip {
 #endif
 

@@ -45,7 +45,7 @@ static Dim g_bidx, g_gdim, g_bdim;
 static std::function<void()> g_body;
 static int g_wg_active = 0, g_sync_arrived = 0, g_sync_site = -1;
 static uint32_t g_sync_gen = 0;
-static uint8_t g_dyn_lds[65536 + 64] __attribute__((aligned(64)));
+static uint8_t g_dyn_lds[98304 + 64] __attribute__((aligned(64)));
 
 const Dim& tidx() { return g_fibers[g_cur].tid; }
 const Dim& bidx() { return g_bidx; }
@@ -296,6 +296,11 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
         const uint32_t grid = nb < 3 ? nb : 3;
         uint32_t counter[8] = {0};
         emu::launch(grid, 128, [&] { snappy_hip::compress_blocks_pair_kernel(w, block_size, stride, counter); });
+    } else if (nb && variant == 7) {
+        // duo form: two-wavefront workgroups (parser + mate), a few workgroups pull blocks from the counter
+        const uint32_t grid = nb < 3 ? nb : 3;
+        uint32_t counter[8] = {0};
+        emu::launch(grid, 128, [&] { snappy_hip::compress_blocks_duo_kernel(w, block_size, stride, counter); });
     } else if (nb && variant == 5) {
         const uint32_t grid = nb < 8 ? 1 : 2;
         std::vector<uint32_t> tables((size_t)grid * 4 * 16384, 0xBEEFBEEFu);

@@ -200,3 +200,34 @@ def test_emulated_stream_form(unordered):
     here = os.path.dirname(os.path.abspath(__file__))
     out = subprocess.run([sys.executable, "-c", _STREAM_STRESS, here], env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+_DUO_STRESS = """
+import sys
+sys.path.insert(0, sys.argv[1])
+import datagen, emu_lib as emu, oracle_lib as oracle
+from conftest import golden_bytes
+text = golden_bytes("plrabn12.txt")
+cases = [golden_bytes("terror2.txt")[:50000], datagen.text_random_interleave(text, 40000), datagen.records(40000),
+         datagen.lz_structured(40000, int(sys.argv[2])), datagen.zeros(9000), b"abcd" + bytes(40000)]
+for data in cases:
+    for bs in (32768, 4097):
+        assert emu.compress(data, bs, 7) == oracle.compress(data, bs), (len(data), bs)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("seed", [0, 4])
+def test_emulated_duo_form_under_shuffled_wave_schedules(seed):
+    """csrc/ablation/k1_duo_form.hpp (round 3, not shipped): the stream form's parser with a second wavefront that analyses
+    the windows ahead of it and emits the windows behind it, talking through an LDS mailbox.  EMU_SHUFFLE runs the fibers of
+    the two wavefronts in random order and in bursts, so requests, answers and segment records interleave differently."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    if seed:
+        env["EMU_SHUFFLE"] = str(seed)
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-c", _DUO_STRESS, here, str(seed)], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]

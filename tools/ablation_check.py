@@ -42,6 +42,9 @@ VARIANTS = [
     # round 2's two-wavefront LDS-table workgroups (csrc/ablation/k1_pair_kernel.hpp): alone, beside global-table wavefronts
     {"SNAPPY_HIP_PAIR_PER_CU": "4", "SNAPPY_HIP_GT_WAVES": "0"}, {"SNAPPY_HIP_PAIR_PER_CU": "3"},
     {"SNAPPY_HIP_PAIR_PER_CU": "1", "SNAPPY_HIP_GT_WAVES": "64"},
+    # round 3's duo form (csrc/ablation/k1_duo_form.hpp: parser + mate wavefront per LDS-table block)
+    {"SNAPPY_HIP_K1_STREAM": "5"}, {"SNAPPY_HIP_K1_STREAM": "5", "SNAPPY_HIP_COMPRESS_VARIANT": "1"},
+    {**TINY_HYBRID, "SNAPPY_HIP_K1_STREAM": "5"},
 ]
 
 
