@@ -566,6 +566,15 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
     K1Forms forms;
     if (int rc = k1_forms_from_env(&forms)) return rc;
     hipStream_t st = (hipStream_t)stream;
+    // A small input -- every block can have an LDS-table wavefront at once, at most one per SIMD -- goes to the LDS-table
+    // kernel alone: its wavefronts run the stream form with nothing else on their SIMD (dickens_like, 312 blocks: K1 1.27 ->
+    // 1.05 ms, profiles/r03_small_inputs.txt); with more blocks than that a second round would follow, and the global-table
+    // kernel's 32 wave slots per CU win.
+    if (variant == kVariantGlobalTable && !getenv("SNAPPY_HIP_COMPRESS_VARIANT") && !getenv("SNAPPY_HIP_LDS_WAVES") &&
+        (env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream) & 1)) {
+        const uint32_t per_cu = std::min<uint32_t>(4u, kLdsPerCu / lds_alloc_bytes(snappy_hip::lds_table_stream_lds_bytes(block_size)));
+        if (nb <= (uint64_t)per_cu * kCus) variant = kVariantLdsTable;
+    }
 #ifdef SNAPPY_ABLATION
     if (variant == kVariantGroup || variant == kVariantLanePerBlock) {
         if (w.count != 1) return fail(SNAPPY_HIP_ERR_ARG, "the lane-per-block and group ablation kernels take one container per launch");

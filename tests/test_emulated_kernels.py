@@ -45,9 +45,8 @@ def test_emulated_long_runs_and_split_copies():
 
 # compress variant = kernel form + 100 * look-ahead code (1 = off, 2 = 4, 3 = 8, 4 = 16, 5 = 64 positions)
 # + 1000 for the masked form, + 2000 for the bulk form, + 3000 for the stream form, + 10000 for the LDS slot filter (see emu_runtime.cpp)
-@pytest.mark.parametrize("cv,dv", [(6, 3), (2501, 3), (12503, 3), (3501, 3), (13503, 3),          # the shipped forms (35xx: stream form)
-                                   (1, 0), (4, 0), (5, 1), (103, 1), (403, 1), (1503, 1), (1501, 0),    # a sample of csrc/ablation/
-                                   (2403, 1), (10503, 1), (22503, 1)])
+@pytest.mark.parametrize("cv,dv", [(2501, 3), (12503, 3), (3501, 3), (13503, 3),                  # the shipped forms (35xx: stream form)
+                                   (6, 3), (1, 0), (5, 1), (403, 1), (1503, 0), (22503, 1)])        # a sample of csrc/ablation/
 def test_emulated_other_variants(cv, dv):
     """LDS-table / lane-per-block compress and LDS-window decompress produce the same bytes."""
     text = golden_bytes("plrabn12.txt")
@@ -137,7 +136,7 @@ print("ok")
 """
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [2])
 def test_emulated_pair_kernel_under_shuffled_wave_schedules(seed):
     """The two-wavefront K1 (compress_blocks_pair_kernel): its wavefronts talk through LDS (token, shared hash table), so
     the emulator runs it with EMU_SHUFFLE -- fibers in random order and whole wavefronts in bursts -- which makes the
@@ -171,13 +170,11 @@ sys.path.insert(0, sys.argv[1])
 import datagen, emu_lib as emu, oracle_lib as oracle
 from conftest import golden_bytes
 text = golden_bytes("plrabn12.txt")
-cases = [golden_bytes("terror2.txt")[:70000], datagen.text_random_interleave(text, 50000), datagen.records(50000), datagen.low_entropy(30000),
-         datagen.lz_structured(50000, 7), datagen.zeros(9000), datagen.periodic(9000, 5), b"abcd" + bytes(40000)]
-cases += [d[:12000] for _, d in datagen.edge_cases(text)]
-for data in cases:
-    for bs in (32768, 4097, 65535, 700):
-        if bs < 4096 and len(data) > 20000:
-            continue
+big = [golden_bytes("terror2.txt")[:50000], datagen.text_random_interleave(text, 40000), datagen.records(40000), datagen.low_entropy(20000),
+       datagen.lz_structured(40000, 7), b"abcd" + bytes(40000)]
+small = [datagen.zeros(9000), datagen.periodic(9000, 5)] + [d[:8000] for _, d in datagen.edge_cases(text)]
+for data, sizes in [(d, (32768, 4097)) for d in big] + [(d, (32768, 65535, 700)) for d in small]:
+    for bs in sizes:
         ref = oracle.compress(data, bs)
         for cv in (3501, 13503):
             assert emu.compress(data, bs, cv) == ref, (len(data), bs, cv)
@@ -217,7 +214,7 @@ print("ok")
 """
 
 
-@pytest.mark.parametrize("seed", [0, 4])
+@pytest.mark.parametrize("seed", [4])
 def test_emulated_duo_form_under_shuffled_wave_schedules(seed):
     """csrc/ablation/k1_duo_form.hpp (round 3, not shipped): the stream form's parser with a second wavefront that analyses
     the windows ahead of it and emits the windows behind it, talking through an LDS mailbox.  EMU_SHUFFLE runs the fibers of

@@ -13,3 +13,12 @@ def test_randomized_streams_match_oracle():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_gpu
     assert fuzz_gpu.run(150, 20261004, verbose=False) == 0
+
+
+def test_randomized_streams_match_oracle_lds_table_kernel_alone(monkeypatch):
+    """The same slice with every block on the LDS-table kernel (the stream form of the parse, snappy_k1_stream.hpp): small
+    inputs would otherwise only see the global-table kernel."""
+    monkeypatch.setenv("SNAPPY_HIP_COMPRESS_VARIANT", "1")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_gpu
+    assert fuzz_gpu.run(120, 20261005, verbose=False) == 0
