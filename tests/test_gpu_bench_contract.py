@@ -39,7 +39,9 @@ def test_bench_json_line_keeps_the_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 and 0 < r["frac"] < 1
-    assert r["traffic"] is None or r["traffic"] > 0
+    assert r["traffic"] is None or (r["traffic"] > 0 and "pmc" in r["traffic_source"])
+    # the same steps with the block index walked from the streams alone: a second timed region, slower by the walk
+    assert 0 < d["value_from_stream_alone"] <= d["value"] * 1.05 and d["ms_per_step_from_stream_alone"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "GB/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert c["gpu_stream_equals_oracle_stream"] is True
