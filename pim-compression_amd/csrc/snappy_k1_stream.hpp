@@ -109,10 +109,6 @@ __device__ __forceinline__ void stream_hash_window(StreamWindow& w, uint32_t shi
     w.e0 = (prod << (32 - shift)) & 0xffff0000u;
 }
 
-// index of the lowest set bit (0..31); all ones when x == 0 (v_ffbl_b32's own convention)
-__device__ __forceinline__ uint32_t first_bit(uint32_t x) { return (uint32_t)__builtin_ffs((int)x) - 1u; }
-__device__ __forceinline__ uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
-
 // the speculative gather of one window: table slot of every lane, 28 candidate bytes where the tag allows a hit
 struct StreamGather {
     uint32_t ent;

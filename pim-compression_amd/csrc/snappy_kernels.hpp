@@ -454,6 +454,10 @@ __constant__ uint32_t kRecip16[64] = {
 // ---------------------------------------------------------------------------
 constexpr uint32_t kDupSlots = 1024;   // bytes of LDS per wavefront for the duplicate-slot test (two tables of 512)
 
+// index of the lowest set bit (0..31); all ones when x == 0 (v_ffbl_b32's own convention)
+__device__ __forceinline__ uint32_t first_bit(uint32_t x) { return (uint32_t)__builtin_ffs((int)x) - 1u; }
+__device__ __forceinline__ uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
 __device__ __forceinline__ uint32_t ctz64_or(unsigned long long x, uint32_t if_zero)
 {
     return x ? (uint32_t)__builtin_ctzll(x) : if_zero;
@@ -572,20 +576,23 @@ struct MaskedWindowState {
         }
         xa = bytes_ahead(win, lane, 4);
         xb = bytes_ahead(win, lane, 8);
-        const uint32_t d0 = k1 ^ xa, d1 = k2 ^ xb;
-        extv = d0 ? ((uint32_t)__builtin_ctz(d0) >> 3) : (d1 ? 4u + ((uint32_t)__builtin_ctz(d1) >> 3) : 8u);
+        // Matching bytes behind the key = the first differing bit of the compared words, found without a branch (the ternary
+        // cascade compiles to five nested exec-mask regions).  first_bit: 0..31, all ones for a zero word, which the ORs keep as
+        // "none" and the minimum ignores.  A lane that is not deep has k3..k6 = 0 and o3..o6 = 1: its second word group differs
+        // at bit 0, which caps it at 8 bytes.
+        const uint32_t t1 = min_u32(first_bit(k1 ^ xa), first_bit(k2 ^ xb) | 32u);
+        uint32_t bits = min_u32(t1, 64u);
         if (kDeep) {
-            if (deep && extv == 8) {
-                const uint32_t d3 = k3 ^ o3, d4 = k4 ^ o4, d5 = k5 ^ o5, d6 = k6 ^ o6;
-                extv = d3 ? 8u + ((uint32_t)__builtin_ctz(d3) >> 3)
-                          : (d4 ? 12u + ((uint32_t)__builtin_ctz(d4) >> 3)
-                                : (d5 ? 16u + ((uint32_t)__builtin_ctz(d5) >> 3) : (d6 ? 20u + ((uint32_t)__builtin_ctz(d6) >> 3) : 24u)));
-            }
-            deepm = __ballot(deep);
+            const uint32_t t2 = min_u32(first_bit(k3 ^ o3), first_bit(k4 ^ o4) | 32u) | 64u;
+            const uint32_t t3 = min_u32(first_bit(k5 ^ o5), first_bit(k6 ^ o6) | 32u) | 128u;
+            bits = min_u32(min_u32(t1, t2), min_u32(t3, 192u));
         }
-        const bool hitl = worth && k0 == win.x0;
-        hit = __ballot(hitl);                          // lanes below r are behind the cursor, lanes >= e not covered
-        longm = __ballot(hitl && extv == (deep ? 24u : 8u));   // hits whose match goes on past the compared bytes
+        extv = bits >> 3;
+        // lane masks from single compares, combined with scalar logic (a ballot of a compound bool costs a v_cndmask + v_cmp more)
+        const unsigned long long worthm = __ballot(worth);
+        deepm = kDeep ? (worthm & __ballot(win.base + lane + 28u <= block_len)) : 0ull;
+        hit = worthm & __ballot(k0 == win.x0);         // lanes below r are behind the cursor, lanes >= e not covered
+        longm = hit & ((deepm & __ballot(extv == 24u)) | (~deepm & __ballot(extv == 8u)));   // hits whose match goes on past the compared bytes
         cov_end = e;
     }
 
