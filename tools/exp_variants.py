@@ -29,7 +29,11 @@ def main():
     assert st == 0
     unit = silesia_mix.build_unit(d_xml.cpu().numpy(), seed=0)
     d_in = silesia_mix.container_from_unit(torch.from_numpy(unit).cuda(), n)
-    ws = shb.CompressWorkspace(n, 32768)
+    if any("SNAPPY_HIP_GT_WIDE=1" in c for c in configs):      # the scratch is sized when the workspace is made
+        os.environ["SNAPPY_HIP_GT_WIDE"] = "1"
+    bs = int(os.environ.get("EXP_BLOCK_SIZE", "32768"))
+    ws = shb.CompressWorkspace(n, bs)
+    os.environ.pop("SNAPPY_HIP_GT_WIDE", None)
     d_stream = torch.empty(ws.stream_capacity(n) + 16, dtype=torch.uint8, device="cuda")
     ref = None
     for cfg in configs:
@@ -57,6 +61,8 @@ def main():
               flush=True)
         for k in kv:
             os.environ.pop(k, None)
+    if bs != 32768:
+        return
     # decompress timing for reference
     st, d_out = shb.decompress_resident(d_stream[:slen])
     total, bs, hdr = shb.parse_header(bytes(d_stream[:10].cpu().numpy()))
