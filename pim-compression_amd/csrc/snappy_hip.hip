@@ -113,7 +113,6 @@ constexpr int kDefaultK1FormLds = 2;    // bulk form for the LDS-table kernel
 constexpr int kDefaultLdsWaves = 768;   // block sizes above 8 KiB: 3 LDS-table wavefronts per CU (3 x 33 KiB) beside 20 global-table ones (3 KiB each: filter + duplicate test)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 constexpr uint32_t kCus = 256, kLdsPerCu = 160u << 10, kWaveSlotsPerCu = 32;
-constexpr int kDefaultGtWide = 0;       // SNAPPY_HIP_GT_WIDE: global-table entries carry the 28 bytes at the position (32 bytes per slot)
 constexpr int kDefaultK1Stream = 1;     // SNAPPY_HIP_K1_STREAM: bit 0 = stream form (snappy_k1_stream.hpp) for the LDS-table kernel (default: +2 % in the mix), bit 1 = for the global-table kernel (-2 %), (ablation build: bit 2 = duo form, two wavefronts per LDS-table block)
 constexpr int kDefaultPairPerCu = 0;    // two-wavefront LDS-table workgroups per CU beside the global-table wavefronts (0 = round 1's one-wavefront LDS-table kernel)
 
@@ -438,15 +437,7 @@ void launch_global_table_kernel(const K1Forms& f, uint32_t grid, hipStream_t st,
     else
         SNAPPY_K1_DISPATCH(launch_k1_global, f.ahead, f.form, grid, st, w, block_size, slot_stride, tables, counter);
 #else
-    const bool stream = env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream) & 2;
-    if (env_int("SNAPPY_HIP_GT_WIDE", kDefaultGtWide)) {
-        if (stream)
-            hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 3, 3>), dim3(grid), dim3(64), 0, st, w, block_size,
-                               slot_stride, tables, counter);
-        else
-            hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 2, 3>), dim3(grid), dim3(64), 0, st, w, block_size,
-                               slot_stride, tables, counter);
-    } else if (stream)
+    if (env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream) & 2)
         hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 3, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
                            slot_stride, tables, counter);
     else
@@ -558,12 +549,7 @@ uint32_t snappy_hip_k1_lds_waves_per_cu(uint32_t block_size)
 uint64_t snappy_hip_compress_scratch_bytes(void)
 {
     // 256-byte header (work counter) + one 64 KiB tagged hash table per resident wavefront (256 CUs x 32 waves)
-#if defined(EXP_DUP_READ) || defined(EXP_DUP_STORE) || defined(EXP_CHAIN_READ) || defined(EXP_HOT_READ) || defined(EXP_HOT_STORE)
-    const uint64_t slot_bytes = 12;
-#else
-    const uint64_t slot_bytes = env_int("SNAPPY_HIP_GT_WIDE", kDefaultGtWide) ? 32 : sizeof(uint32_t);
-#endif
-    return 256 + (uint64_t)kGlobalTableWaves * snappy_hip::kMaxTableEntries * slot_bytes;
+    return 256 + (uint64_t)kGlobalTableWaves * snappy_hip::kMaxTableEntries * sizeof(uint32_t);
 }
 
 // K1 over a batch of containers (count >= 1, every container non-empty and validated by the callers below)

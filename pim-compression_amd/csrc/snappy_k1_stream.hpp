@@ -119,23 +119,15 @@ template <class Table>
 __device__ __forceinline__ void stream_issue_gather(StreamGather& g, const Table& table, const StreamWindow& w,
                                                     const uint8_t* __restrict__ blk, uint32_t lane)
 {
-    if constexpr (Table::kWide) {                              // the slot holds the candidate's bytes: one round trip, no fetch
-        const WideEntry e = table.load_entry(w.h0);
-        g.ent = e.b.w;
-        g.ka = e.a;
-        g.kb = e.b;
-        g.worthm = ~0ull;
-    } else {
-        const uint32_t mine_l = w.e0 | (w.base + lane);
-        g.ent = table.load_lane(w.h0, mine_l);
-        const bool worth = !Table::certain_miss(g.ent, mine_l);
-        g.worthm = __ballot(worth);
-        g.ka = g.kb = make_uint4(0, 0, 0, 0);
-        if (worth) {                                           // candidate <= position, and position + 32 <= block length
-            const uint8_t* __restrict__ c = blk + (g.ent & 0xffffu);
-            g.ka = ld128(c);
-            g.kb = ld128(c + 16);
-        }
+    const uint32_t mine_l = w.e0 | (w.base + lane);
+    g.ent = table.load_lane(w.h0, mine_l);
+    const bool worth = !Table::certain_miss(g.ent, mine_l);
+    g.worthm = __ballot(worth);
+    g.ka = g.kb = make_uint4(0, 0, 0, 0);
+    if (worth) {                                               // candidate <= position, and position + 32 <= block length
+        const uint8_t* __restrict__ c = blk + (g.ent & 0xffffu);
+        g.ka = ld128(c);
+        g.kb = ld128(c + 16);
     }
 }
 
@@ -318,25 +310,12 @@ __device__ __forceinline__ bool has_run_of_34(unsigned long long m)
     return (r & (m >> 32) & (m >> 33)) != 0;
 }
 
-// insert position `pos` (scalar form of StreamWindow's h0 / e0)
+// insert position `pos` whose 4 bytes are x (scalar form of StreamWindow's h0 / e0)
 template <class Table>
-__device__ __forceinline__ void stream_put(const Table& table, const uint8_t* __restrict__ blk, uint32_t avail, uint32_t pos,
-                                           uint32_t shift, uint32_t lane)
+__device__ __forceinline__ void stream_put(const Table& table, uint32_t x, uint32_t pos, uint32_t shift, uint32_t lane)
 {
-    const uint32_t prod = uld32(blk + pos) * kHashMul;
-    if constexpr (Table::kWide)
-        table.put_entry(prod >> shift, wide_content_at(blk, pos, avail), lane);
-    else
-        table.put(prod >> shift, ((prod << (32 - shift)) & 0xffff0000u) | pos, lane);
-}
-// insert this lane's position of window `w`
-template <class Table>
-__device__ __forceinline__ void stream_store(const Table& table, const StreamWindow& w, uint32_t lane)
-{
-    if constexpr (Table::kWide)
-        table.store_entry(w.h0, w.a, make_uint4(w.b.x, w.b.y, w.b.z, w.base + lane));
-    else
-        table.store_lane(w.h0, w.e0 | (w.base + lane));
+    const uint32_t prod = x * kHashMul;
+    table.put(prod >> shift, ((prod << (32 - shift)) & 0xffff0000u) | pos, lane);
 }
 
 // What the stream form hands to "the other half" of a window's work -- the duplicate analysis in front of the parse and the
@@ -588,15 +567,15 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
             // than their partners); the few that are left -- longer chains, hidden partners -- one by one in lane order.
             {
                 const unsigned long long later = dup.nf | dup.cx;
-                if (__builtin_amdgcn_inverse_ballot_w64(C & ~later)) stream_store(table, cur, lane);
+                if (__builtin_amdgcn_inverse_ballot_w64(C & ~later)) table.store_lane(cur.h0, cur.e0 | (cur.base + lane));
                 __builtin_amdgcn_wave_barrier();
                 const unsigned long long second = C & dup.nf & ~dup.deep & ~dup.cx;
                 if (second) {
-                    if (__builtin_amdgcn_inverse_ballot_w64(second)) stream_store(table, cur, lane);
+                    if (__builtin_amdgcn_inverse_ballot_w64(second)) table.store_lane(cur.h0, cur.e0 | (cur.base + lane));
                     __builtin_amdgcn_wave_barrier();
                 }
                 for (unsigned long long dd = C & (dup.deep | dup.cx); dd; dd &= dd - 1) {
-                    if (__builtin_amdgcn_inverse_ballot_w64(dd & (~dd + 1))) stream_store(table, cur, lane);
+                    if (__builtin_amdgcn_inverse_ballot_w64(dd & (~dd + 1))) table.store_lane(cur.h0, cur.e0 | (cur.base + lane));
                     __builtin_amdgcn_wave_barrier();
                 }
             }
@@ -612,7 +591,7 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
                 cur = nxt;
                 stream_hash_window(cur, shift);
                 if (r_out > kWave) {                             // :391-392 for the copy that ended in this window
-                    if (lane == r_out - kWave - 1u) stream_store(table, cur, lane);
+                    if (lane == r_out - kWave - 1u) table.store_lane(cur.h0, cur.e0 | (cur.base + lane));
                     __builtin_amdgcn_wave_barrier();
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -634,7 +613,7 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
                 ip += long_len;                                  // the cursor behind the copy
                 skip = 31;
                 if (ip < limit) {                                // :388-392
-                    stream_put(table, blk, avail, ip - 1u, shift, lane);
+                    stream_put(table, uld32(blk + ip - 1u), ip - 1u, shift, lane);
                     restart = (ip & ~63u) + kStreamRoom <= limit;
                 }
                 PROF_LAP(9);                                     // 9: long copies
@@ -642,7 +621,7 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
             }
             if (!go) {
                 if (r_out > kWave)                               // the "ip - 1" lane of a copy that ended beyond this window
-                    stream_put(table, blk, avail, ip - 1u, shift, lane);
+                    stream_put(table, uld32(blk + ip - 1u), ip - 1u, shift, lane);
                 break;
             }
             // ---------------- analyse(W+1) ----------------
@@ -668,11 +647,8 @@ __device__ __forceinline__ void compress_one_block_stream(const uint8_t* __restr
     const uint32_t ts = table_entries_for(n);                    // get_hash_table, :139-146 (+ shift, :288)
     const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
     const uint32_t e_zero = (n >= kInputMargin) ? (((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u) : 0u;
-    Table table = table_in.with_empty(e_zero);
-    if (n >= kInputMargin) {
-        if constexpr (Table::kWide) table.set_empty(blk, in_len - start);
-        table.init(ts, e_zero, lane);
-    }
+    const Table table = table_in.with_empty(e_zero);
+    if (n >= kInputMargin) table.init(ts, e_zero, lane);
     if (Mate::kAnalysesInPlace)
         for (uint32_t i = lane; i < 2u * kSlots; i += kWave) ((lds_words_t)dup_scratch)[i] = 0;   // analyse() keeps its tables zeroed
     __builtin_amdgcn_wave_barrier();

@@ -313,7 +313,6 @@ namespace snappy_hip {
 // answered from a register (the initial entry), its line is never fetched, and the table needs no per-block
 // initialisation at all: whatever an earlier block left in the scratch is unreachable until this block overwrites it.
 struct FilteredGlobalTable {
-    static constexpr bool kWide = false;
     uint32_t* __restrict__ t;
     lds_words_t written;        // kMaxTableEntries / 32 words
     uint32_t empty;             // tag(position 0) << 16 | 0
@@ -339,146 +338,21 @@ struct FilteredGlobalTable {
     {
         uint32_t hv = h;
         SNAPPY_PIN(hv);
-#ifdef EXP_U16_TABLE
-        ((uint16_t*)t)[hv] = (uint16_t)entry;
-#else
         t[hv] = entry;
-#endif
         if (lane == 0) lds_or(written + (h >> 5), 1u << (h & 31u));
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ static bool certain_miss(uint32_t old, uint32_t entry) { return ((old ^ entry) >> 16) != 0; }
-#if defined(EXP_DUP_READ) || defined(EXP_DUP_STORE) || defined(EXP_CHAIN_READ) || defined(EXP_HOT_READ) || defined(EXP_HOT_STORE)
-    static constexpr size_t kExpOff = (size_t)8192 * 16384;     // the second half of a doubled scratch
-    __device__ __forceinline__ uint32_t load_lane(uint32_t h, uint32_t = 0) const
-    {
-        if (!is_written(h)) return empty;
-        uint32_t v = t[h];
-#ifdef EXP_DUP_READ
-        for (int k = 1; k <= EXP_DUP_READ; ++k) {
-            uint32_t d = t[kExpOff * k + h];
-            asm volatile("v_and_b32 %0, 0, %0" : "+v"(d));
-            v |= d;
-        }
-#endif
-#ifdef EXP_HOT_READ
-        {   // as EXP_DUP_READ=1, but from 1 KiB per wavefront (hits in L2), read past the L1 (agent scope)
-            uint32_t d = __hip_atomic_load(t + kExpOff + (h & 255u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("v_and_b32 %0, 0, %0" : "+v"(d));
-            v |= d;
-        }
-#endif
-#ifdef EXP_CHAIN_READ
-        uint32_t d = t[kExpOff + (v & 0x3fffu)];
-        asm volatile("v_and_b32 %0, 0, %0" : "+v"(d));
-        v |= d;
-#endif
-        return v;
-    }
-    __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const
-    {
-        t[h] = entry;
-#ifdef EXP_DUP_STORE
-        for (int k = 1; k <= EXP_DUP_STORE; ++k) t[kExpOff * k + h] = entry;
-#endif
-#ifdef EXP_HOT_STORE
-        t[kExpOff + (h & 255u)] = entry;
-#endif
-        lds_or(written + (h >> 5), 1u << (h & 31u));
-    }
-#elif defined(EXP_U16_TABLE)
-    // experiment: positions only (u16), half the footprint, no tag: every written slot's candidate is fetched
-    __device__ __forceinline__ uint32_t load_lane(uint32_t h, uint32_t mine = 0) const
-    {
-        return (mine & 0xffff0000u) | (is_written(h) ? (uint32_t)((const uint16_t*)t)[h] : 0u);
-    }
-    __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const
-    {
-        ((uint16_t*)t)[h] = (uint16_t)entry;
-        lds_or(written + (h >> 5), 1u << (h & 31u));
-    }
-#else
     __device__ __forceinline__ uint32_t load_lane(uint32_t h, uint32_t = 0) const { return is_written(h) ? t[h] : empty; }
     __device__ __forceinline__ void store_lane(uint32_t h, uint32_t entry) const
     {
         t[h] = entry;      // (write-through `sc1` and non-temporal stores measured the same: DESIGN 3.1)
         lds_or(written + (h >> 5), 1u << (h & 31u));
     }
-#endif
     __device__ __forceinline__ FilteredGlobalTable with_empty(uint32_t e) const { return FilteredGlobalTable{t, written, e}; }
 };
 
-// The global table with CONTENT (round 3): a slot holds the 28 bytes at the inserted position and the position itself
-// (32 bytes), not just the position.  A probe's hit test (:348) and the first 24 bytes of find_match_length (:176-193) are
-// then answered by the table read alone: the gather needs ONE round trip instead of two (slot -> candidate bytes), and
-// the candidate fetches -- 29.5 per 64-byte window, 42 lines of the ~99 the tagged form requests
-// (profiles/r03_k1_lines_breakdown.txt) -- are gone; only matches of 28+ bytes still read the input (match_extend).  The
-// inserting lane has those bytes in registers (they are its own window).  Same LDS filter, no tag (the 4-byte key itself is
-// in the entry).  Scratch: 512 KiB per wavefront instead of 64 KiB.
-struct WideEntry {
-    uint4 a;                    // le32 at position + 0 / 4 / 8 / 12
-    uint4 b;                    // le32 at position + 16 / 20 / 24, and the position
-};
-// le32 at blk + off, the address clamped so that the load stays inside `avail` bytes (avail >= 4)
-__device__ __forceinline__ uint32_t ld32_clamped(const uint8_t* __restrict__ blk, uint32_t off, uint32_t avail)
-{
-    const uint32_t last = avail - 4u;
-    return ld32(blk + (off < last ? off : last));
-}
-// the content a WideEntry holds for position `pos` (bytes past the end of the input read as whatever the clamped loads
-// return: they can only be compared by a probe that has 28 bytes itself, i.e. never -- see DESIGN 3.1d)
-__device__ __forceinline__ WideEntry wide_content_at(const uint8_t* __restrict__ blk, uint32_t pos, uint32_t avail)
-{
-    WideEntry e;
-    e.a = make_uint4(ld32_clamped(blk, pos, avail), ld32_clamped(blk, pos + 4u, avail), ld32_clamped(blk, pos + 8u, avail),
-                     ld32_clamped(blk, pos + 12u, avail));
-    e.b = make_uint4(ld32_clamped(blk, pos + 16u, avail), ld32_clamped(blk, pos + 20u, avail), ld32_clamped(blk, pos + 24u, avail), pos);
-    return e;
-}
-
-struct WideGlobalTable {
-    static constexpr bool kWide = true;
-    uint4* __restrict__ t;      // two per slot
-    lds_words_t written;        // kMaxTableEntries / 32 words
-    uint4 ea, eb;               // what an unwritten slot answers: candidate position 0 (:145 + :346) with the block's first bytes
-    __device__ __forceinline__ void init(uint32_t entries, uint32_t, uint32_t lane) const
-    {
-        for (uint32_t i = lane; i < entries / 32; i += kWave) written[i] = 0;
-        __builtin_amdgcn_wave_barrier();
-    }
-    __device__ __forceinline__ bool is_written(uint32_t h) const { return (written[h >> 5] >> (h & 31u)) & 1u; }
-    __device__ __forceinline__ WideEntry load_entry(uint32_t h) const
-    {
-        WideEntry e{ea, eb};
-        if (is_written(h)) {
-            e.a = t[2u * h];
-            e.b = t[2u * h + 1u];
-        }
-        return e;
-    }
-    __device__ __forceinline__ void store_entry(uint32_t h, uint4 a, uint4 b) const
-    {
-        t[2u * h] = a;
-        t[2u * h + 1u] = b;
-        lds_or(written + (h >> 5), 1u << (h & 31u));
-    }
-    __device__ __forceinline__ void put_entry(uint32_t h, const WideEntry& e, uint32_t lane) const   // uniform arguments
-    {
-        if (lane == 0) store_entry(h, e.a, e.b);
-        __builtin_amdgcn_wave_barrier();
-    }
-    __device__ __forceinline__ void set_empty(const uint8_t* __restrict__ blk, uint64_t left)
-    {
-        const WideEntry e = wide_content_at(blk, 0, (left < 0x7fffffffull) ? (uint32_t)left : 0x7fffffffu);
-        ea = e.a;
-        eb = e.b;
-    }
-    __device__ __forceinline__ static bool certain_miss(uint32_t, uint32_t) { return false; }
-    __device__ __forceinline__ WideGlobalTable with_empty(uint32_t) const { return *this; }
-};
-
 struct LdsTable {               // the reference's own layout: u16 positions, in LDS (no room for tags: 32 KiB per block)
-    static constexpr bool kWide = false;
     uint16_t* t;
     __device__ __forceinline__ void init(uint32_t entries, uint32_t, uint32_t lane) const
     {
@@ -628,17 +502,14 @@ struct MaskedWindowState {
     unsigned long long deepm = 0;   // wave-uniform: lanes whose extv covers 24 bytes (saturates at 24) instead of 8
     unsigned long long inserted = 0;// wave-uniform: window lanes whose position has been inserted (bulk form)
     uint32_t xa = 0, xb = 0;        // per lane: le32 at position + 4 / + 8
-    uint32_t o3 = 0, o4 = 0, o5 = 0, o6 = 0;   // per lane: le32 at position + 12 / 16 / 20 / 24 (content-carrying tables only)
     uint32_t cov_end = 0;           // lanes in [gather start, cov_end) are resolved
     bool dup_valid = false;
-    bool content_valid = false;     // xa, xb, o3..o6 belong to the current window (content-carrying tables: needed by every insert)
 
     __device__ __forceinline__ void invalidate()
     {
         cov_end = 0;
         hit = 0;
         dup_valid = false;
-        content_valid = false;
         inserted = 0;
     }
 
@@ -666,13 +537,7 @@ struct MaskedWindowState {
         const unsigned long long gm = kWithDup ? lane_range(r, e - r) : (lane_range(r, e - r) & ~dup);
         const bool g = __builtin_amdgcn_inverse_ballot_w64(gm);
         const uint32_t mine_l = win.e0 | (win.base + lane);
-        [[maybe_unused]] WideEntry wide{};
-        if constexpr (Table::kWide) {
-            if (g) wide = table.load_entry(win.h0);
-            ent = wide.b.w;
-        } else {
-            if (g) ent = table.load_lane(win.h0, mine_l);
-        }
+        if (g) ent = table.load_lane(win.h0, mine_l);
         // The LDS duplicate test (three dependent LDS round trips) runs underneath the longest loads of the gather: the table
         // loads when the table is in global memory, the candidate loads when it is in LDS (its entries arrive at once).
         constexpr bool kDupUnderCandidates = std::is_same<Table, LdsTable>::value;
@@ -686,31 +551,7 @@ struct MaskedWindowState {
         uint32_t k0 = 0, k1 = 0, k2 = 0;
         const bool deep = kDeep && worth && (win.base + lane + 28u <= block_len);   // candidate < position, so it has 28 too
         uint32_t k3 = 0, k4 = 0, k5 = 0, k6 = 0, o3 = 1, o4 = 1, o5 = 1, o6 = 1;
-        if constexpr (Table::kWide) {
-            // the entry IS the candidate's content; this lane's own bytes behind the first twelve are needed by every insert of
-            // the window as well as by the comparison, so all lanes load them
-            if (!content_valid) {
-                this->o3 = win.load_at(win.base + 12u, lane);      // (load_at(pos, lane) reads at pos + lane, clamped to the input)
-                this->o4 = win.load_at(win.base + 16u, lane);
-                this->o5 = win.load_at(win.base + 20u, lane);
-                this->o6 = win.load_at(win.base + 24u, lane);
-            }
-            if (worth) {
-                k0 = wide.a.x;
-                k1 = wide.a.y;
-                k2 = wide.a.z;
-                if (deep) {
-                    k3 = wide.a.w;
-                    k4 = wide.b.x;
-                    k5 = wide.b.y;
-                    k6 = wide.b.z;
-                    o3 = this->o3;
-                    o4 = this->o4;
-                    o5 = this->o5;
-                    o6 = this->o6;
-                }
-            }
-        } else if (worth) {                           // every stored position p has p + 16 <= block length
+        if (worth) {                                  // every stored position p has p + 16 <= block length
             const uint8_t* __restrict__ c = win.blk + (ent & 0xffffu);
             k0 = ld32(c);
             k1 = ld32(c + 4);
@@ -735,7 +576,6 @@ struct MaskedWindowState {
         }
         xa = bytes_ahead(win, lane, 4);
         xb = bytes_ahead(win, lane, 8);
-        content_valid = true;
         // Matching bytes behind the key = the first differing bit of the compared words, found without a branch (the ternary
         // cascade compiles to five nested exec-mask regions).  first_bit: 0..31, all ones for a zero word, which the ORs keep as
         // "none" and the minimum ignores.  A lane that is not deep has k3..k6 = 0 and o3..o6 = 1: its second word group differs
@@ -756,28 +596,7 @@ struct MaskedWindowState {
         cov_end = e;
     }
 
-    // insert the positions of the lanes in `m` (each its own slot); a content-carrying table gets the lanes' 28 bytes too,
-    // from the window's registers (loaded here for a window no gather has visited: the "ip - 1" insert behind a copy that
-    // ended in it, :391-392)
-    __device__ __forceinline__ void insert(const Table& table, const CursorWindow& win, unsigned long long m, uint32_t lane)
-    {
-        if constexpr (Table::kWide) {
-            if (!content_valid) {
-                xa = win.load_at(win.base + 4u, lane);
-                xb = win.load_at(win.base + 8u, lane);
-                o3 = win.load_at(win.base + 12u, lane);
-                o4 = win.load_at(win.base + 16u, lane);
-                o5 = win.load_at(win.base + 20u, lane);
-                o6 = win.load_at(win.base + 24u, lane);
-                content_valid = true;
-            }
-            if (__builtin_amdgcn_inverse_ballot_w64(m))
-                table.store_entry(win.h0, make_uint4(win.x0, xa, xb, o3), make_uint4(o4, o5, o6, win.base + lane));
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            commit(table, win, m, lane);
-        }
-    }
+    // insert the positions of the lanes in `m` (each its own slot)
     __device__ __forceinline__ static void commit(const Table& table, const CursorWindow& win, unsigned long long m, uint32_t lane)
     {
         if (__builtin_amdgcn_inverse_ballot_w64(m)) table.store_lane(win.h0, win.e0 | (win.base + lane));
@@ -1006,7 +825,7 @@ __device__ __forceinline__ bool bulk_run(const uint8_t* __restrict__ blk, uint32
                     const uint32_t cnt = (uint32_t)__builtin_popcountll(pre);
                     skip += cnt;
                     if (p == kWave || ((stopm >> p) & 1ull)) {               // no hit at this stride level here
-                        st.insert(table, win, pre, lane);                // (no DUP lane among them: those are stops)
+                        State::commit(table, win, pre, lane);                // (no DUP lane among them: those are stops)
                         st.inserted |= pre;
                         ip += cnt * stride;
                         continue;
@@ -1087,16 +906,16 @@ __device__ __forceinline__ bool bulk_run(const uint8_t* __restrict__ blk, uint32
                 unsigned long long endl = COV & ~(interior >> 1);                              // last lane of each copy
                 if (why == 0 && (r > kWave || done)) endl &= ~(1ull << (r_end - 1));           // the last copy's is not (yet) due
                 C |= endl;
-                st.insert(table, win, C & ~st.dup, lane);
+                State::commit(table, win, C & ~st.dup, lane);
                 st.inserted |= C;
                 for (unsigned long long d = C & st.dup; d; d &= d - 1)                         // shared slots: in position order
-                    st.insert(table, win, d & (~d + 1), lane);
+                    State::commit(table, win, d & (~d + 1), lane);
 
                 if (H) emit_segment(dst, blk, op, next_emit, win.base, win.x0, st.ent, st.extv, H, COV, why == 0, r, lane);
                 if (done) break;
                 if (why == 0 && r > kWave) {                     // :391-392 for a copy that ended in a later window
                     if (win.ensure(ip - 1, lane)) st.invalidate();
-                    st.insert(table, win, 1ull << (ip - 1 - win.base), lane);
+                    State::commit(table, win, 1ull << (ip - 1 - win.base), lane);
                     st.inserted |= 1ull << (ip - 1 - win.base);
                 }
                 if (!need_single) continue;
@@ -1114,7 +933,7 @@ __device__ __forceinline__ bool bulk_run(const uint8_t* __restrict__ blk, uint32
                 const uint32_t hr = win.hash_at(ip);
                 J = __ballot(win.h0 == hr) & st.inserted & ((1ull << r) - 1ull);
             }
-            st.insert(table, win, 1ull << r, lane);
+            State::commit(table, win, 1ull << r, lane);
             st.inserted |= 1ull << r;
             if (J) {
                 const uint32_t j = 63u - (uint32_t)__builtin_clzll(J);
@@ -1149,7 +968,7 @@ __device__ __forceinline__ bool bulk_run(const uint8_t* __restrict__ blk, uint32
             next_emit = ip;
             if (ip >= limit) break;                              // :388-389
             if (win.ensure(ip - 1, lane)) st.invalidate();
-            st.insert(table, win, 1ull << (ip - 1 - win.base), lane);   // :391-392
+            State::commit(table, win, 1ull << (ip - 1 - win.base), lane);   // :391-392
             st.inserted |= 1ull << (ip - 1 - win.base);
             skip = 31;
         }
@@ -1184,11 +1003,8 @@ __device__ __forceinline__ void compress_one_block_bulk(const uint8_t* __restric
     const uint32_t shift = (uint32_t)__builtin_clz(ts) + 1;
     // "empty" = candidate position 0 (:346 on a zeroed table), carrying position 0's tag
     const uint32_t e_zero = (n >= kInputMargin) ? (((uld32(blk) * kHashMul) << (32 - shift)) & 0xffff0000u) : 0u;
-    Table table = table_in.with_empty(e_zero);
-    if (n >= kInputMargin) {
-        if constexpr (Table::kWide) table.set_empty(blk, in_len - start);
-        table.init(ts, e_zero, lane);
-    }
+    const Table table = table_in.with_empty(e_zero);
+    if (n >= kInputMargin) table.init(ts, e_zero, lane);
     __builtin_amdgcn_wave_barrier();
     ParseState ps;
     if (n >= kInputMargin) {  // :301
@@ -1326,20 +1142,14 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
     __shared__ __attribute__((aligned(16))) uint32_t slot_state[kFilter == 2 ? kMaxTableEntries / 16 : (kFilter ? kMaxTableEntries / 32 : 4)];
     const uint32_t lane = threadIdx.x;
 #ifdef SNAPPY_ABLATION
-    using Narrow = typename std::conditional<kFilter == 2, ClassFilteredGlobalTable,
-                                             typename std::conditional<kFilter == 1, FilteredGlobalTable, TaggedGlobalTable>::type>::type;
+    using Table = typename std::conditional<kFilter == 2, ClassFilteredGlobalTable,
+                                            typename std::conditional<kFilter == 1, FilteredGlobalTable, TaggedGlobalTable>::type>::type;
 #else
-    static_assert((kForm == 2 || kForm == 3) && (kFilter == 1 || kFilter == 3), "the product ships the bulk and stream forms behind the slot filter; other forms need -DSNAPPY_ABLATION");
-    using Narrow = FilteredGlobalTable;
+    static_assert((kForm == 2 || kForm == 3) && kFilter == 1, "the product ships the bulk and stream forms behind the slot filter; other forms need -DSNAPPY_ABLATION");
+    using Table = FilteredGlobalTable;
 #endif
-    using Table = typename std::conditional<kFilter == 3, WideGlobalTable, Narrow>::type;   // 3: entries carry the content
     Table table;
-    if constexpr (kFilter == 3) {
-        table.t = (uint4*)table_scratch + (size_t)blockIdx.x * (2u * kMaxTableEntries);
-        table.written = (lds_words_t)slot_state;
-    } else {
-        table.t = table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
-    }
+    table.t = table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
     if constexpr (kFilter == 1) {
         table.written = (lds_words_t)slot_state;
         table.empty = 0;

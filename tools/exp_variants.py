@@ -29,11 +29,8 @@ def main():
     assert st == 0
     unit = silesia_mix.build_unit(d_xml.cpu().numpy(), seed=0)
     d_in = silesia_mix.container_from_unit(torch.from_numpy(unit).cuda(), n)
-    if any("SNAPPY_HIP_GT_WIDE=1" in c for c in configs):      # the scratch is sized when the workspace is made
-        os.environ["SNAPPY_HIP_GT_WIDE"] = "1"
     bs = int(os.environ.get("EXP_BLOCK_SIZE", "32768"))
     ws = shb.CompressWorkspace(n, bs)
-    os.environ.pop("SNAPPY_HIP_GT_WIDE", None)
     d_stream = torch.empty(ws.stream_capacity(n) + 16, dtype=torch.uint8, device="cuda")
     ref = None
     for cfg in configs:
