@@ -15,6 +15,7 @@ namespace snappy_hip {
 // the same value to the same address (one write on the wire, no exec-mask save/restore).  uni() sits between the
 // load and the store, so every lane has read before any lane writes.
 struct TaggedGlobalTable {      // u32 entries in the global scratch: tag << 16 | position
+    static constexpr bool kCollectiveStore = false;
     uint32_t* __restrict__ t;
     __device__ __forceinline__ void init(uint32_t entries, uint32_t entry_zero, uint32_t lane) const
     {
@@ -52,6 +53,7 @@ struct TaggedGlobalTable {      // u32 entries in the global scratch: tag << 16 
 // caller gets an entry with the complemented tag, which certain_miss() rejects.  About 60 % of the probes of written
 // slots end here.
 struct ClassFilteredGlobalTable {
+    static constexpr bool kCollectiveStore = false;
     uint32_t* __restrict__ t;
     lds_words_t cls;            // kMaxTableEntries / 16 words
     uint32_t empty;             // tag(position 0) << 16 | 0

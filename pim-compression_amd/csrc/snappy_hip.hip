@@ -113,7 +113,8 @@ constexpr int kDefaultK1FormLds = 2;    // bulk form for the LDS-table kernel
 constexpr int kDefaultLdsWaves = 768;   // block sizes above 8 KiB: 3 LDS-table wavefronts per CU (3 x 33 KiB) beside 20 global-table ones (3 KiB each: filter + duplicate test)
 constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
 constexpr uint32_t kCus = 256, kLdsPerCu = 160u << 10, kWaveSlotsPerCu = 32;
-constexpr int kDefaultK1Stream = 1;     // SNAPPY_HIP_K1_STREAM: bit 0 = stream form (snappy_k1_stream.hpp) for the LDS-table kernel (default: +2 % in the mix), bit 1 = for the global-table kernel (-2 %), (ablation build: bit 2 = duo form, two wavefronts per LDS-table block)
+constexpr int kDefaultGtCache = 512;    // SNAPPY_HIP_GT_CACHE: slots of the write-back cache in LDS in front of the global table, for blocks with full-size hash tables; 0 = none (the ablation build also has 256 and 1024)
+constexpr int kDefaultK1Stream = 1;     // SNAPPY_HIP_K1_STREAM: bit 0 = stream form (snappy_k1_stream.hpp) for the LDS-table kernel (default: +2 % in the mix), bit 1 = for the global-table kernel (default with the slot cache: +3 % there, -2 % without), (ablation build: bit 2 = duo form, two wavefronts per LDS-table block)
 constexpr int kDefaultPairPerCu = 0;    // two-wavefront LDS-table workgroups per CU beside the global-table wavefronts (0 = round 1's one-wavefront LDS-table kernel)
 
 // Work counters for persistent kernels: a ring in the code object's own global memory (one copy per device), so launches
@@ -263,9 +264,36 @@ int env_int(const char* name, int fallback)
 // every allocation up to 1 KiB (a multiple of every granule CDNA parts have used)
 uint32_t lds_alloc_bytes(uint32_t bytes) { return (bytes + 1023u) & ~1023u; }
 
+// K1's defaults depend on the block size: blocks of more than 8 KiB have the full 16384-slot table, whose global-table form
+// runs at the HBM's random-access rate; there the slot cache and the stream form pay (profiles/r03_gt_cache_block_size_sweep.txt)
+int gt_cache_slots(uint32_t block_size)
+{
+#ifdef SNAPPY_ABLATION
+    const int def = 0;
+#else
+    const int def = block_size > 8192u ? kDefaultGtCache : 0;
+#endif
+    const int v = env_int("SNAPPY_HIP_GT_CACHE", def);
+#ifdef SNAPPY_ABLATION
+    return (v == 256 || v == 512 || v == 1024) ? v : 0;          // other sizes: sweeps (tools/gt_cache_sweep.sh)
+#else
+    return v ? 512 : 0;
+#endif
+}
+int k1_stream_forms(uint32_t block_size)
+{
+#ifdef SNAPPY_ABLATION
+    (void)block_size;
+    return env_int("SNAPPY_HIP_K1_STREAM", 0);
+#else
+    return env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream | (gt_cache_slots(block_size) ? 2 : 0));
+#endif
+}
+
 uint32_t default_lds_waves_per_cu(uint32_t block_size)
 {
-    const uint32_t per_wave = lds_alloc_bytes(env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream) & 1
+    if (gt_cache_slots(block_size)) return 1;    // beside cached global-table wavefronts: one LDS-table wavefront per CU
+    const uint32_t per_wave = lds_alloc_bytes(k1_stream_forms(block_size) & 1
                                                   ? snappy_hip::lds_table_stream_lds_bytes(block_size)
                                                   : snappy_hip::lds_table_kernel_lds_bytes(block_size, true));
     if (per_wave > (24u << 10)) return kDefaultLdsWaves / 256;
@@ -416,7 +444,7 @@ void launch_lds_table_kernel(const K1Forms& f, uint32_t grid, hipStream_t st, co
     else
         SNAPPY_K1_DISPATCH(launch_k1_lds, f.ahead_lds, f.form_lds, grid, f.extra_lds, st, w, block_size, slot_stride, counter);
 #else
-    if (env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream) & 1)
+    if (k1_stream_forms(block_size) & 1)
         hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<64, 3>), dim3(grid), dim3(64),
                            snappy_hip::lds_table_stream_lds_bytes(block_size), st, w, block_size, slot_stride, counter);
     else
@@ -429,6 +457,25 @@ void launch_lds_table_kernel(const K1Forms& f, uint32_t grid, hipStream_t st, co
 void launch_global_table_kernel(const K1Forms& f, uint32_t grid, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size,
                                 uint32_t slot_stride, uint32_t* tables, uint32_t* counter)
 {
+    // the slot cache in front of the global table (CachedGlobalTable), bulk or stream form
+    const int cache_slots = gt_cache_slots(block_size);
+    const bool stream_form = (k1_stream_forms(block_size) & 2) != 0;
+#define SNAPPY_GT_CACHED(SLOTS)                                                                                                    \
+    if (cache_slots == SLOTS) {                                                                                                    \
+        if (stream_form)                                                                                                           \
+            hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 3, 1, SLOTS>), dim3(grid), dim3(64), 0, st, w, \
+                               block_size, slot_stride, tables, counter);                                                          \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 2, 1, SLOTS>), dim3(grid), dim3(64), 0, st, w, \
+                               block_size, slot_stride, tables, counter);                                                          \
+        return;                                                                                                                    \
+    }
+    SNAPPY_GT_CACHED(512)
+#ifdef SNAPPY_ABLATION
+    SNAPPY_GT_CACHED(1024)
+    SNAPPY_GT_CACHED(256)
+#endif
+#undef SNAPPY_GT_CACHED
 #ifdef SNAPPY_ABLATION
     if (f.filter == 2)
         launch_k1_global_class_filtered(grid, st, w, block_size, slot_stride, tables, counter);
@@ -437,7 +484,7 @@ void launch_global_table_kernel(const K1Forms& f, uint32_t grid, hipStream_t st,
     else
         SNAPPY_K1_DISPATCH(launch_k1_global, f.ahead, f.form, grid, st, w, block_size, slot_stride, tables, counter);
 #else
-    if (env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream) & 2)
+    if (stream_form)
         hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 3, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
                            slot_stride, tables, counter);
     else
@@ -571,7 +618,7 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
     // 1.05 ms, profiles/r03_small_inputs.txt); with more blocks than that a second round would follow, and the global-table
     // kernel's 32 wave slots per CU win.
     if (variant == kVariantGlobalTable && !getenv("SNAPPY_HIP_COMPRESS_VARIANT") && !getenv("SNAPPY_HIP_LDS_WAVES") &&
-        (env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream) & 1)) {
+        (k1_stream_forms(block_size) & 1)) {
         const uint32_t per_cu = std::min<uint32_t>(4u, kLdsPerCu / lds_alloc_bytes(snappy_hip::lds_table_stream_lds_bytes(block_size)));
         if (nb <= (uint64_t)per_cu * kCus) variant = kVariantLdsTable;
     }
@@ -634,9 +681,11 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
     uint32_t* counter = static_cast<uint32_t*>(d_scratch);
     uint32_t* tables = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_scratch) + 256);
     HIP_TRY(hipMemsetAsync(counter, 0, 32, st));   // [0] next block, [4] blocks compressed by wavefronts with an LDS table
-    const int k1_stream = env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream);
-    const uint32_t g_wave_bytes = (k1_stream & 2) ? (2u << 10) + snappy_hip::stream_scratch_bytes(snappy_hip::kStreamSlotsGlobal)
-                                                  : ((forms.form ? 1u : 0u) + (forms.filter == 2 ? 4u : (forms.filter ? 2u : 0u))) << 10;
+    const int k1_stream = k1_stream_forms(block_size);
+    const int gt_cache = gt_cache_slots(block_size);
+    const uint32_t g_wave_bytes = gt_cache ? ((k1_stream & 2) ? 4u << 10 : 3u << 10) + 4u * (uint32_t)gt_cache
+                                  : (k1_stream & 2) ? (2u << 10) + snappy_hip::stream_scratch_bytes(snappy_hip::kStreamSlotsGlobal)
+                                                    : ((forms.form ? 1u : 0u) + (forms.filter == 2 ? 4u : (forms.filter ? 2u : 0u))) << 10;
     // fork / join around the caller's stream: `lds_launch` goes to the helper stream, the global-table kernel stays on `st`
     auto co_run = [&](uint32_t g, const std::function<void(hipStream_t)>& lds_launch) -> int {
         CoRunResources* cr = nullptr;

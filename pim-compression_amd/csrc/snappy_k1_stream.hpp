@@ -315,7 +315,21 @@ template <class Table>
 __device__ __forceinline__ void stream_put(const Table& table, uint32_t x, uint32_t pos, uint32_t shift, uint32_t lane)
 {
     const uint32_t prod = x * kHashMul;
-    table.put(prod >> shift, ((prod << (32 - shift)) & 0xffff0000u) | pos, lane);
+    if constexpr (Table::kCollectiveStore)
+        table.store_masked(1ull, prod >> shift, pos, lane);
+    else
+        table.put(prod >> shift, ((prod << (32 - shift)) & 0xffff0000u) | pos, lane);
+}
+// insert the positions of the lanes in `m` of window `w` (each its own slot)
+template <class Table>
+__device__ __forceinline__ void stream_store(const Table& table, const StreamWindow& w, unsigned long long m, uint32_t lane)
+{
+    if constexpr (Table::kCollectiveStore) {
+        table.store_masked(m, w.h0, w.base + lane, lane);
+    } else {
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) table.store_lane(w.h0, w.e0 | (w.base + lane));
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // What the stream form hands to "the other half" of a window's work -- the duplicate analysis in front of the parse and the
@@ -567,17 +581,10 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
             // than their partners); the few that are left -- longer chains, hidden partners -- one by one in lane order.
             {
                 const unsigned long long later = dup.nf | dup.cx;
-                if (__builtin_amdgcn_inverse_ballot_w64(C & ~later)) table.store_lane(cur.h0, cur.e0 | (cur.base + lane));
-                __builtin_amdgcn_wave_barrier();
+                stream_store(table, cur, C & ~later, lane);
                 const unsigned long long second = C & dup.nf & ~dup.deep & ~dup.cx;
-                if (second) {
-                    if (__builtin_amdgcn_inverse_ballot_w64(second)) table.store_lane(cur.h0, cur.e0 | (cur.base + lane));
-                    __builtin_amdgcn_wave_barrier();
-                }
-                for (unsigned long long dd = C & (dup.deep | dup.cx); dd; dd &= dd - 1) {
-                    if (__builtin_amdgcn_inverse_ballot_w64(dd & (~dd + 1))) table.store_lane(cur.h0, cur.e0 | (cur.base + lane));
-                    __builtin_amdgcn_wave_barrier();
-                }
+                if (second) stream_store(table, cur, second, lane);
+                for (unsigned long long dd = C & (dup.deep | dup.cx); dd; dd &= dd - 1) stream_store(table, cur, dd & (~dd + 1), lane);
             }
             ip = cur.base + r_out;
             skip = skip_out;
@@ -591,8 +598,7 @@ __device__ __forceinline__ void stream_run(const uint8_t* __restrict__ blk, uint
                 cur = nxt;
                 stream_hash_window(cur, shift);
                 if (r_out > kWave) {                             // :391-392 for the copy that ended in this window
-                    if (lane == r_out - kWave - 1u) table.store_lane(cur.h0, cur.e0 | (cur.base + lane));
-                    __builtin_amdgcn_wave_barrier();
+                    stream_store(table, cur, 1ull << (r_out - kWave - 1u), lane);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 stream_load_window(nxt, blk, cur.base + 64u, last16, lane);

@@ -313,6 +313,7 @@ namespace snappy_hip {
 // answered from a register (the initial entry), its line is never fetched, and the table needs no per-block
 // initialisation at all: whatever an earlier block left in the scratch is unreachable until this block overwrites it.
 struct FilteredGlobalTable {
+    static constexpr bool kCollectiveStore = false;
     uint32_t* __restrict__ t;
     lds_words_t written;        // kMaxTableEntries / 32 words
     uint32_t empty;             // tag(position 0) << 16 | 0
@@ -352,7 +353,67 @@ struct FilteredGlobalTable {
     __device__ __forceinline__ FilteredGlobalTable with_empty(uint32_t e) const { return FilteredGlobalTable{t, written, e}; }
 };
 
+// The global table behind a write-back cache of slots in LDS (round 3).  The global-table kernel runs at the HBM's
+// random-access rate: per 64-byte window 35 slot reads and 20 table stores, each a DRAM burst of its own
+// (profiles/r03_k1_global_table_bound.txt).  Table stores have strong temporal locality -- a 4-gram that was just inserted is
+// inserted or probed again soon -- so a direct-mapped cache of kSlots recent stores takes most of them
+// (tools/slot_cache_sim.c on the benchmark data, 2,048 slots: 35.1 -> 10.2 slot reads and 19.9 -> 9.3 stores per window
+// reach the global table).  Only stores allocate (a gather's reads are mostly speculation); a slot displaced from the cache
+// is written to the global table then.  The slot's value is: its cache word if the cache holds the slot, else the global
+// entry if the slot was ever written (`written` bit), else position 0 (:145).  Global entries are positions only (u16):
+// a content tag would have to be recomputed at eviction, and candidates are recent input (L2 hits).
+//   cache word = (slot + 1) << 16 | position; 0 = free
+template <uint32_t kSlots>
+struct CachedGlobalTable {
+    static constexpr bool kCollectiveStore = true;
+    uint16_t* __restrict__ t;   // kMaxTableEntries positions per wavefront
+    lds_words_t written;        // kMaxTableEntries / 32 words
+    lds_words_t cache;          // kSlots words
+    __device__ __forceinline__ void init(uint32_t entries, uint32_t, uint32_t lane) const
+    {
+        for (uint32_t i = lane; i < entries / 32; i += kWave) written[i] = 0;
+        for (uint32_t i = lane; i < kSlots; i += kWave) cache[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ bool is_written(uint32_t h) const { return (written[h >> 5] >> (h & 31u)) & 1u; }
+    __device__ __forceinline__ static bool certain_miss(uint32_t, uint32_t) { return false; }
+    __device__ __forceinline__ CachedGlobalTable with_empty(uint32_t) const { return *this; }
+    // the slot's position under the probing lane's own tag (every written slot's candidate is compared)
+    __device__ __forceinline__ uint32_t load_lane(uint32_t h, uint32_t mine) const
+    {
+        const uint32_t w = cache[h & (kSlots - 1u)];
+        const bool wr = is_written(h);
+        uint32_t pos = w & 0xffffu;
+        if ((w >> 16) != h + 1u) pos = wr ? (uint32_t)t[h] : 0u;
+        return (mine & 0xffff0000u) | pos;
+    }
+    // All lanes call; the lanes in `m` (each its own slot) insert `pos`.  Lanes of one call that share a cache word: one
+    // of them gets it (read back, not assumed), the others write through.
+    __device__ __forceinline__ void store_masked(unsigned long long m, uint32_t h, uint32_t pos, uint32_t) const
+    {
+        const bool s = __builtin_amdgcn_inverse_ballot_w64(m);
+        const uint32_t idx = h & (kSlots - 1u), mine = ((h + 1u) << 16) | (pos & 0xffffu);
+        uint32_t old = 0;
+        if (s) old = cache[idx];
+        __builtin_amdgcn_wave_barrier();
+        if (s) {
+            cache[idx] = mine;
+            lds_or(written + (h >> 5), 1u << (h & 31u));
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t now = mine;
+        if (s) now = cache[idx];
+        const bool lost = now != mine;
+        // the displaced slot goes out first, then the lanes that lost (one of them may be the displaced slot's new value)
+        if (s && !lost && old != 0u && (old >> 16) != h + 1u) t[(old >> 16) - 1u] = (uint16_t)old;
+        __builtin_amdgcn_wave_barrier();
+        if (lost) t[h] = (uint16_t)pos;
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
 struct LdsTable {               // the reference's own layout: u16 positions, in LDS (no room for tags: 32 KiB per block)
+    static constexpr bool kCollectiveStore = false;
     uint16_t* t;
     __device__ __forceinline__ void init(uint32_t entries, uint32_t, uint32_t lane) const
     {
@@ -599,8 +660,12 @@ struct MaskedWindowState {
     // insert the positions of the lanes in `m` (each its own slot)
     __device__ __forceinline__ static void commit(const Table& table, const CursorWindow& win, unsigned long long m, uint32_t lane)
     {
-        if (__builtin_amdgcn_inverse_ballot_w64(m)) table.store_lane(win.h0, win.e0 | (win.base + lane));
-        __builtin_amdgcn_wave_barrier();
+        if constexpr (Table::kCollectiveStore) {
+            table.store_masked(m, win.h0, win.base + lane, lane);
+        } else {
+            if (__builtin_amdgcn_inverse_ballot_w64(m)) table.store_lane(win.h0, win.e0 | (win.base + lane));
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 };
 
@@ -782,6 +847,18 @@ __device__ __forceinline__ bool bulk_run(const uint8_t* __restrict__ blk, uint32
         uint32_t ip = ps.ip;
         uint32_t skip = ps.skip;
         for (uint32_t iter = 0;; ++iter) {
+#if defined(EXP_EXTRA_SALU) && !defined(SNAPPY_EMU)
+            {   // experiment: EXP_EXTRA_SALU independent scalar instructions per iteration
+                uint32_t sx = iter;
+                asm volatile(".rept %1\n s_add_u32 %0, %0, 1\n .endr" : "+s"(sx) : "n"(EXP_EXTRA_SALU) : "scc");
+            }
+#endif
+#if defined(EXP_EXTRA_VALU) && !defined(SNAPPY_EMU)
+            {
+                uint32_t vx = lane;
+                asm volatile(".rept %1\n v_add_u32 %0, %0, 1\n .endr" : "+v"(vx) : "n"(EXP_EXTRA_VALU));
+            }
+#endif
             const uint32_t stride = skip >> 5;
             const uint32_t step = stride ? stride : 1u;
             if (ip + step > limit) break;                        // :342-343 / :388-389
@@ -1133,24 +1210,32 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const K1B
     }
 }
 
-template <uint32_t kAhead, int kForm = 0, int kFilter = 0>
+template <uint32_t kAhead, int kForm = 0, int kFilter = 0, uint32_t kCacheSlots = 0>
 __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const K1Batch w, uint32_t block_size, uint32_t slot_stride,
                                                                           uint32_t* table_scratch, uint32_t* next_block)
 {
     const uint32_t num_blocks = w.first_block[w.count];
     __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kForm == 3 ? stream_scratch_bytes(kStreamSlotsGlobal) : (kForm ? kDupSlots : 16)];
     __shared__ __attribute__((aligned(16))) uint32_t slot_state[kFilter == 2 ? kMaxTableEntries / 16 : (kFilter ? kMaxTableEntries / 32 : 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t slot_cache[kCacheSlots ? kCacheSlots : 4];
     const uint32_t lane = threadIdx.x;
 #ifdef SNAPPY_ABLATION
-    using Table = typename std::conditional<kFilter == 2, ClassFilteredGlobalTable,
-                                            typename std::conditional<kFilter == 1, FilteredGlobalTable, TaggedGlobalTable>::type>::type;
+    using Narrow = typename std::conditional<kFilter == 2, ClassFilteredGlobalTable,
+                                             typename std::conditional<kFilter == 1, FilteredGlobalTable, TaggedGlobalTable>::type>::type;
 #else
     static_assert((kForm == 2 || kForm == 3) && kFilter == 1, "the product ships the bulk and stream forms behind the slot filter; other forms need -DSNAPPY_ABLATION");
-    using Table = FilteredGlobalTable;
+    using Narrow = FilteredGlobalTable;
 #endif
+    using Table = typename std::conditional<kCacheSlots != 0, CachedGlobalTable<(kCacheSlots ? kCacheSlots : 1024u)>, Narrow>::type;
     Table table;
-    table.t = table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
-    if constexpr (kFilter == 1) {
+    if constexpr (kCacheSlots != 0) {
+        table.t = (uint16_t*)table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
+        table.written = (lds_words_t)slot_state;
+        table.cache = (lds_words_t)slot_cache;
+    } else {
+        table.t = table_scratch + (size_t)blockIdx.x * kMaxTableEntries;
+    }
+    if constexpr (kFilter == 1 && kCacheSlots == 0) {
         table.written = (lds_words_t)slot_state;
         table.empty = 0;
     }

@@ -217,7 +217,8 @@ extern "C" {
 // Runs compress_blocks_kernel + scan + gather on the CPU emulator.  Returns stream length.
 // variant = kernel form (1 LDS table, 3 global table, 4 lane-per-block, 5 group) + 100 * look-ahead code
 // (0 = EMU_K1_AHEAD, 1 = off, 2 = 4, 3 = 8, 4 = 16, 5 = 64) + 1000 for the masked form, + 2000 for the bulk form (chunk = look-ahead, needs > 0), + 3000 for the stream form,
-// + 10000 for the LDS slot filter in front of the global table, + 20000 for the tag-class filter (bulk form only)
+// + 10000 for the LDS slot filter in front of the global table, + 20000 for the tag-class filter (bulk form only),
+// + 40000 / + 50000 for the write-back slot cache of 512 / 256 slots (bulk and stream form, look-ahead 64)
 #define EMU_AHEAD_DISPATCH(code, CALL)                         \
     switch (code) {                                            \
     case 1: { constexpr uint32_t kA = 0; CALL; } break;        \
@@ -264,7 +265,17 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
         std::vector<uint32_t> tables((size_t)grid * 16384, 0xBEEFBEEFu);
         uint32_t counter = 0;
         emu::launch(grid, 64, [&] {
-            if (filter_kind == 2) {
+            if (filter_kind == 4) {              // write-back cache of slots in LDS in front of u16 global entries
+                if (form == 3)
+                    snappy_hip::compress_blocks_global_table_kernel<64, 3, 1, 512>(w, block_size, stride, tables.data(), &counter);
+                else
+                    snappy_hip::compress_blocks_global_table_kernel<64, 2, 1, 512>(w, block_size, stride, tables.data(), &counter);
+            } else if (filter_kind == 5) {
+                if (form == 3)
+                    snappy_hip::compress_blocks_global_table_kernel<64, 3, 1, 256>(w, block_size, stride, tables.data(), &counter);
+                else
+                    snappy_hip::compress_blocks_global_table_kernel<64, 2, 1, 256>(w, block_size, stride, tables.data(), &counter);
+            } else if (filter_kind == 2) {
                 EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 2, 2>(
                                                    w, block_size, stride, tables.data(), &counter)));
             } else if (filtered) {

@@ -45,7 +45,7 @@ def lib():
     return _LIB
 
 
-def compress(data, block_size=32768, variant=12503):   # the product default: bulk form + slot filter, look-ahead 64
+def compress(data, block_size=32768, variant=43503):   # the product default for blocks of more than 8 KiB: global table behind the slot cache, stream form
     a = np.frombuffer(data, dtype=np.uint8).copy() if len(data) else np.zeros(1, dtype=np.uint8)
     n = len(data)
     nb = (n + block_size - 1) // block_size

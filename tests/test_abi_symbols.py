@@ -108,4 +108,6 @@ def test_k2_back_references_use_global_not_flat_instructions(tmp_path):
     kernels = set(re.findall(r"^\s*\.amdhsa_kernel (\S+)", text, re.M))
     k1 = sorted(k for k in kernels if "_blocks_" in k and "decompress" not in k)
     assert len([k for k in kernels if "decompress_blocks_kernel" in k]) == 1, sorted(kernels)
-    assert 2 <= len(k1) <= 4, k1     # the LDS-table and the global-table kernel, each in the bulk and / or the stream form
+    # the LDS-table kernel and the global-table kernel, each in the bulk and the stream form; the global-table kernel also behind
+    # its slot cache (the default for blocks of more than 8 KiB)
+    assert 2 <= len(k1) <= 6, k1

@@ -44,8 +44,10 @@ def test_emulated_long_runs_and_split_copies():
 
 
 # compress variant = kernel form + 100 * look-ahead code (1 = off, 2 = 4, 3 = 8, 4 = 16, 5 = 64 positions)
-# + 1000 for the masked form, + 2000 for the bulk form, + 3000 for the stream form, + 10000 for the LDS slot filter (see emu_runtime.cpp)
-@pytest.mark.parametrize("cv,dv", [(2501, 3), (12503, 3), (3501, 3), (13503, 3),                  # the shipped forms (35xx: stream form)
+# + 1000 for the masked form, + 2000 for the bulk form, + 3000 for the stream form, + 10000 for the LDS slot filter,
+# + 40000 / + 50000 for the write-back slot cache of 512 / 256 slots in front of the global table (see emu_runtime.cpp)
+@pytest.mark.parametrize("cv,dv", [(2501, 3), (12503, 3), (3501, 3), (13503, 3),                  # the shipped forms (35xx: stream form;
+                                   (43503, 3), (53503, 3), (42503, 3),                              #  4xxxx / 5xxxx: slot cache of 512 / 256)
                                    (6, 3), (1, 0), (5, 1), (403, 1), (1503, 0), (22503, 1)])        # a sample of csrc/ablation/
 def test_emulated_other_variants(cv, dv):
     """LDS-table / lane-per-block compress and LDS-window decompress produce the same bytes."""
@@ -176,7 +178,7 @@ small = [datagen.zeros(9000), datagen.periodic(9000, 5)] + [d[:8000] for _, d in
 for data, sizes in [(d, (32768, 4097)) for d in big] + [(d, (32768, 65535, 700)) for d in small]:
     for bs in sizes:
         ref = oracle.compress(data, bs)
-        for cv in (3501, 13503):
+        for cv in (3501, 43503):
             assert emu.compress(data, bs, cv) == ref, (len(data), bs, cv)
 print("ok")
 """

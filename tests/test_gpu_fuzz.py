@@ -22,3 +22,12 @@ def test_randomized_streams_match_oracle_lds_table_kernel_alone(monkeypatch):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_gpu
     assert fuzz_gpu.run(120, 20261005, verbose=False) == 0
+
+
+def test_randomized_streams_match_oracle_global_table_kernel_alone(monkeypatch):
+    """The same slice with every block on the global-table kernel: behind its slot cache and in the stream form for blocks of
+    more than 8 KiB, plain (slot filter, bulk form) below; inputs this small would otherwise go to the LDS-table kernel."""
+    monkeypatch.setenv("SNAPPY_HIP_LDS_WAVES", "0")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_gpu
+    assert fuzz_gpu.run(120, 20261006, verbose=False) == 0

@@ -400,7 +400,13 @@ TINY_HYBRID = {"SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11", "SNAPPY
                                  # the stream form (snappy_k1_stream.hpp) and the bulk form, for either kind of table
                                  {"SNAPPY_HIP_K1_STREAM": "0"}, {"SNAPPY_HIP_K1_STREAM": "1"}, {"SNAPPY_HIP_K1_STREAM": "2"},
                                  {"SNAPPY_HIP_K1_STREAM": "3"}, {"SNAPPY_HIP_K1_STREAM": "3", "SNAPPY_HIP_COMPRESS_VARIANT": "1"},
-                                 {"SNAPPY_HIP_K1_STREAM": "3", "SNAPPY_HIP_LDS_WAVES": "0"}, dict(TINY_HYBRID, SNAPPY_HIP_K1_STREAM="3")])
+                                 {"SNAPPY_HIP_K1_STREAM": "3", "SNAPPY_HIP_LDS_WAVES": "0"}, dict(TINY_HYBRID, SNAPPY_HIP_K1_STREAM="3"),
+                                 # the global-table kernel behind its slot cache (default for blocks of more than 8 KiB) in the
+                                 # bulk form, and without the cache in either form
+                                 {"SNAPPY_HIP_LDS_WAVES": "0", "SNAPPY_HIP_K1_STREAM": "1"},
+                                 {"SNAPPY_HIP_LDS_WAVES": "0", "SNAPPY_HIP_GT_CACHE": "0"},
+                                 {"SNAPPY_HIP_LDS_WAVES": "0", "SNAPPY_HIP_GT_CACHE": "0", "SNAPPY_HIP_K1_STREAM": "3"},
+                                 dict(TINY_HYBRID, SNAPPY_HIP_GT_CACHE="0")])
 def test_kernel_variants_bit_exact(shb, env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
