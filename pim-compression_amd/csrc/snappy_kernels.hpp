@@ -393,21 +393,21 @@ struct CachedGlobalTable {
     {
         const bool s = __builtin_amdgcn_inverse_ballot_w64(m);
         const uint32_t idx = h & (kSlots - 1u), mine = ((h + 1u) << 16) | (pos & 0xffffu);
-        uint32_t old = 0;
-        if (s) old = cache[idx];
+        const uint32_t old = cache[idx];                         // (every lane reads: no exec-mask region for a load)
         __builtin_amdgcn_wave_barrier();
         if (s) {
             cache[idx] = mine;
             lds_or(written + (h >> 5), 1u << (h & 31u));
         }
         __builtin_amdgcn_wave_barrier();
-        uint32_t now = mine;
-        if (s) now = cache[idx];
-        const bool lost = now != mine;
+        const uint32_t now = cache[idx];
+        const bool lost = s && now != mine;
         // the displaced slot goes out first, then the lanes that lost (one of them may be the displaced slot's new value)
         if (s && !lost && old != 0u && (old >> 16) != h + 1u) t[(old >> 16) - 1u] = (uint16_t)old;
         __builtin_amdgcn_wave_barrier();
-        if (lost) t[h] = (uint16_t)pos;
+        if (__ballot(lost)) {                                    // rare: two stores of one call met in a cache word
+            if (lost) t[h] = (uint16_t)pos;
+        }
         __builtin_amdgcn_wave_barrier();
     }
 };
