@@ -847,18 +847,6 @@ __device__ __forceinline__ bool bulk_run(const uint8_t* __restrict__ blk, uint32
         uint32_t ip = ps.ip;
         uint32_t skip = ps.skip;
         for (uint32_t iter = 0;; ++iter) {
-#if defined(EXP_EXTRA_SALU) && !defined(SNAPPY_EMU)
-            {   // experiment: EXP_EXTRA_SALU independent scalar instructions per iteration
-                uint32_t sx = iter;
-                asm volatile(".rept %1\n s_add_u32 %0, %0, 1\n .endr" : "+s"(sx) : "n"(EXP_EXTRA_SALU) : "scc");
-            }
-#endif
-#if defined(EXP_EXTRA_VALU) && !defined(SNAPPY_EMU)
-            {
-                uint32_t vx = lane;
-                asm volatile(".rept %1\n v_add_u32 %0, %0, 1\n .endr" : "+v"(vx) : "n"(EXP_EXTRA_VALU));
-            }
-#endif
             const uint32_t stride = skip >> 5;
             const uint32_t step = stride ? stride : 1u;
             if (ip + step > limit) break;                        // :342-343 / :388-389
