@@ -76,6 +76,20 @@ def test_host_helpers_match_reference_framing():
         assert len(c) - 4 <= shb.slot_stride(bs) + 6
 
 
+def test_default_k1_launch_shape_by_block_size(monkeypatch):
+    """Host logic of K1's default launch (no GPU needed): blocks of more than 8 KiB have full-size hash tables; their
+    global-table wavefronts run behind the slot cache with ONE LDS-table wavefront per CU beside them; smaller blocks keep
+    round 2's shape, as many LDS-table wavefronts as fit beside eight global-table ones."""
+    import snappy_hip_binding as shb
+    for k in ("SNAPPY_HIP_GT_CACHE", "SNAPPY_HIP_K1_STREAM", "SNAPPY_HIP_LDS_WAVES"):
+        monkeypatch.delenv(k, raising=False)
+    assert [shb.k1_lds_waves_per_cu(bs) for bs in (4096, 8192, 8193, 16384, 32768, 65535)] == [10, 6, 1, 1, 1, 1]
+    monkeypatch.setenv("SNAPPY_HIP_GT_CACHE", "0")            # without the cache: three 36 KiB tables per CU
+    assert shb.k1_lds_waves_per_cu(32768) == 3
+    monkeypatch.setenv("SNAPPY_HIP_LDS_WAVES", "1024")
+    assert shb.k1_lds_waves_per_cu(32768) == 4
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a HIP device the drop-in entry points must fail loudly, never compute on the CPU."""
     import torch
