@@ -1,6 +1,8 @@
 """CPU tests: the UNMODIFIED HIP kernel source (pim-compression_amd/csrc/snappy_kernels.hpp) compiled
 for the lockstep wave emulator in tests/emu and compared with the oracle.  This is logic coverage for the
 GPU-less container; the real parity tests are the -m gpu ones through the C ABI."""
+import os
+
 import pytest
 
 import datagen
@@ -138,6 +140,7 @@ print("ok")
 """
 
 
+@pytest.mark.skipif(os.environ.get("SNAPPY_TEST_ABLATION") != "1", reason="ablation kernel (csrc/ablation/): set SNAPPY_TEST_ABLATION=1")
 @pytest.mark.parametrize("seed", [2])
 def test_emulated_pair_kernel_under_shuffled_wave_schedules(seed):
     """The two-wavefront K1 (compress_blocks_pair_kernel): its wavefronts talk through LDS (token, shared hash table), so
@@ -216,6 +219,7 @@ print("ok")
 """
 
 
+@pytest.mark.skipif(os.environ.get("SNAPPY_TEST_ABLATION") != "1", reason="ablation kernel (csrc/ablation/): set SNAPPY_TEST_ABLATION=1")
 @pytest.mark.parametrize("seed", [4])
 def test_emulated_duo_form_under_shuffled_wave_schedules(seed):
     """csrc/ablation/k1_duo_form.hpp (round 3, not shipped): the stream form's parser with a second wavefront that analyses
