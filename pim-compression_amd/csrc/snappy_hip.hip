@@ -115,7 +115,7 @@ constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIM
 constexpr uint32_t kCus = 256, kLdsPerCu = 160u << 10, kWaveSlotsPerCu = 32;
 constexpr int kDefaultGtCache = 512;    // SNAPPY_HIP_GT_CACHE: slots of the write-back cache in LDS in front of the global table, for blocks with full-size hash tables; 0 = none (the ablation build also has 256 and 1024)
 constexpr int kDefaultK1Stream = 1;     // SNAPPY_HIP_K1_STREAM: bit 0 = stream form (snappy_k1_stream.hpp) for the LDS-table kernel (default: +2 % in the mix), bit 1 = for the global-table kernel (default with the slot cache: +3 % there, -2 % without), (ablation build: bit 2 = duo form, two wavefronts per LDS-table block)
-constexpr int kDefaultPairPerCu = 0;    // two-wavefront LDS-table workgroups per CU beside the global-table wavefronts (0 = round 1's one-wavefront LDS-table kernel)
+[[maybe_unused]] constexpr int kDefaultPairPerCu = 0;    // two-wavefront LDS-table workgroups per CU beside the global-table wavefronts (0 = round 1's one-wavefront LDS-table kernel)
 
 // Work counters for persistent kernels: a ring in the code object's own global memory (one copy per device), so launches
 // need no allocation.  Each launch takes the next slot of its device's ring, zeroes it on its stream and leaves an event
