@@ -101,7 +101,8 @@ int for_each_device(int count, const std::function<int(int)>& fn)
 
 constexpr int kVariantLdsTable = 1, kVariantGlobalTable = 3;
 #ifdef SNAPPY_ABLATION
-constexpr int kVariantLanePerBlock = 4, kVariantGroup = 5;
+constexpr int kVariantLanePerBlock = 4, kVariantGroup = 5, kVariantOracle = 6;
+const uint32_t* g_oracle_records = nullptr;    // device array, one u32 per input position (tools/gate_b_ceiling.py)
 #endif
 constexpr int kDefaultDecompressVariant = 1;   // the concurrent LDS+global form (2) measured no faster for K2
 constexpr int kDefaultK1Ahead = 64;     // look-ahead of the global-table form (64 = the whole cursor window)
@@ -568,6 +569,11 @@ uint32_t snappy_hip_parse_header(const uint8_t* src, uint64_t avail, uint32_t* t
     return a + b;
 }
 
+#ifdef SNAPPY_ABLATION
+// ablation build only: the records OracleTable / RecMate read (csrc/ablation/k1_oracle_table.hpp)
+void snappy_hip_debug_set_oracle_records(const uint32_t* d_records) { g_oracle_records = d_records; }
+#endif
+
 #ifdef SNAPPY_PROF
 // probe builds only (tools/prof_stream.py): read / reset the lap timers of the stream form
 int snappy_hip_debug_prof(unsigned long long* out, int reset)
@@ -623,6 +629,17 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
         if (nb <= (uint64_t)per_cu * kCus) variant = kVariantLdsTable;
     }
 #ifdef SNAPPY_ABLATION
+    if (variant == kVariantOracle) {     // ceiling experiment (csrc/ablation/k1_oracle_table.hpp): the table answered from host-made records
+        if (w.count != 1 || !g_oracle_records || !d_scratch)
+            return fail(SNAPPY_HIP_ERR_ARG, "variant 6 takes one container, a scratch and snappy_hip_debug_set_oracle_records()");
+        uint32_t* counter = static_cast<uint32_t*>(d_scratch);
+        HIP_TRY(hipMemsetAsync(counter, 0, 32, st));
+        const uint32_t waves = (uint32_t)std::min<uint64_t>(nb, (uint64_t)env_int("SNAPPY_HIP_GT_WAVES", 20 * 256));
+        hipLaunchKernelGGL(snappy_hip::compress_blocks_oracle_kernel, dim3(waves), dim3(64), 0, st, w, block_size, slot_stride,
+                           g_oracle_records, counter);
+        HIP_TRY(hipGetLastError());
+        return SNAPPY_HIP_OK;
+    }
     if (variant == kVariantGroup || variant == kVariantLanePerBlock) {
         if (w.count != 1) return fail(SNAPPY_HIP_ERR_ARG, "the lane-per-block and group ablation kernels take one container per launch");
         const uint8_t* d_in = w.in[0];

@@ -68,6 +68,10 @@ struct StreamProf {};
 #define PROF_FLUSH() ((void)0)
 #endif
 
+// a table type that declares kGathersOnce (the ceiling experiment's) wants every window gathered exactly once
+template <class T, class = void> struct table_gathers_once : std::false_type {};
+template <class T> struct table_gathers_once<T, std::void_t<decltype(T::kGathersOnce)>> : std::true_type {};
+
 constexpr uint32_t kStreamRoom = 192;   // the stream form takes a window when base + kStreamRoom <= limit: every lane can be
                                         // probed (:342), has 32 bytes to load, and no copy of < 64 bytes reaches the limit
 // slots per table of analyse() (two tables of dwords): 4 KiB of LDS beside the 32 KiB hash table, 2 KiB beside the 2 KiB
@@ -674,7 +678,8 @@ __device__ __forceinline__ void compress_one_block_stream(const uint8_t* __restr
             }
             STREAM_STAT(5);
             // at least one step of the bulk form, then on to the next window boundary at stride 1
-            const bool over = bulk_run<Table, 64>(blk, avail, n, shift, dst, table, lane, dup_scratch, ps, (ps.ip | 63u) + 1u);
+            const bool over = bulk_run<Table, 64, table_gathers_once<Table>::value>(blk, avail, n, shift, dst, table, lane, dup_scratch, ps,
+                                                                                    (ps.ip | 63u) + 1u);
             if (Mate::kAnalysesInPlace)
                 for (uint32_t i = lane; i < 2u * kSlots; i += kWave) ((lds_words_t)dup_scratch)[i] = 0;   // its race tables used the bytes
             __builtin_amdgcn_wave_barrier();

@@ -827,7 +827,9 @@ struct ParseState {
 // The bulk parse from `ps` on: steps until the scan is over (returns true: the caller emits the remainder, :405-410) or --
 // after at least one step -- the cursor has reached stop_ip at stride 1 (returns false; the table, the slot and `ps` are
 // exactly the reference's state in front of the probe at ps.ip, so any form of the parse can take over).
-template <class Table, uint32_t kChunk>
+// kAtWindowEntry (the ceiling experiment's table, csrc/ablation/k1_oracle_table.hpp): hand over only where the cursor has just
+// entered a window this form has not gathered, so that every window is gathered once, at its first probe.
+template <class Table, uint32_t kChunk, bool kAtWindowEntry = false>
 __device__ __forceinline__ bool bulk_run(const uint8_t* __restrict__ blk, uint32_t avail, uint32_t n, uint32_t shift,
                                          uint8_t* __restrict__ dst, const Table table, uint32_t lane, lds_bytes_t dup_scratch,
                                          ParseState& ps, uint32_t stop_ip)
@@ -850,7 +852,7 @@ __device__ __forceinline__ bool bulk_run(const uint8_t* __restrict__ blk, uint32
             const uint32_t stride = skip >> 5;
             const uint32_t step = stride ? stride : 1u;
             if (ip + step > limit) break;                        // :342-343 / :388-389
-            if (iter && ip >= stop_ip && skip < 64u) {
+            if (iter && ip >= stop_ip && skip < 64u && (!kAtWindowEntry || ip >= win.base + 64u)) {
                 finished = false;
                 break;
             }
@@ -1280,6 +1282,12 @@ namespace snappy_hip {
 #ifdef SNAPPY_ABLATION
 }  // namespace snappy_hip
 #include "ablation/k1_duo_form.hpp"
+namespace snappy_hip {
+#endif
+
+#ifdef SNAPPY_ABLATION
+}  // namespace snappy_hip
+#include "ablation/k1_oracle_table.hpp"
 namespace snappy_hip {
 #endif
 

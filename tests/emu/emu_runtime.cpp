@@ -349,6 +349,37 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
     return stream_len;
 }
 
+// The ceiling experiment's kernel (csrc/ablation/k1_oracle_table.hpp): the table answered from `rec` (n + 64 records
+// made by tools/gate_b_records.c).  Returns the stream length.
+uint64_t emu_compress_oracle(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_t* stream, uint64_t stream_cap, const uint32_t* rec)
+{
+    const uint64_t need = 4ull + 32ull + block_size + block_size / 6;
+    const uint32_t stride = (uint32_t)((need + 15) & ~15ull);
+    const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
+    if (!nb || stream_cap < 10 + (uint64_t)nb * stride) return 0;
+    std::vector<uint8_t> slots((size_t)nb * stride + 64, 0xAA);
+    std::vector<uint32_t> bytes(nb + 1, 0);
+    std::vector<uint64_t> offsets(nb + 1, 0);
+    uint64_t stream_len = 0;
+    std::vector<uint8_t> inbuf(n + 64, 0x55);
+    memcpy(inbuf.data(), in, n);
+    snappy_hip::K1Batch w{};
+    w.count = 1;
+    w.first_block[0] = 0;
+    w.first_block[1] = nb;
+    w.in[0] = inbuf.data();
+    w.in_len[0] = n;
+    w.slots[0] = slots.data();
+    w.block_bytes[0] = bytes.data();
+    uint32_t counter = 0;
+    emu::launch(nb < 3 ? nb : 3, 64, [&] { snappy_hip::compress_blocks_oracle_kernel(w, block_size, stride, rec, &counter); });
+    emu::launch(1, 1024, [&] {
+        snappy_hip::scan_block_bytes_kernel(bytes.data(), nb, (uint32_t)n, block_size, stream, offsets.data(), &stream_len);
+    });
+    emu::launch(nb, 256, [&] { snappy_hip::gather_slots_kernel(slots.data(), stride, bytes.data(), offsets.data(), stream, nb); });
+    return stream_len;
+}
+
 uint64_t emu_compress(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_t* stream, uint64_t stream_cap)
 {
     return emu_compress_variant(in, n, block_size, stream, stream_cap, 12503);
