@@ -432,6 +432,7 @@ uint64_t oracle_compress_mt(const uint8_t *src, uint64_t n, uint32_t block_size,
 	if (nthreads > 256)
 		nthreads = 256;
 	pthread_t tid[256];
+	unsigned char created[256];
 	struct mt_job jobs[256];
 	uint64_t per = (nblocks + nthreads - 1) / nthreads;
 	int started = 0;
@@ -443,11 +444,15 @@ uint64_t oracle_compress_mt(const uint8_t *src, uint64_t n, uint32_t block_size,
 			l = nblocks;
 		jobs[t] = (struct mt_job){ .src = src, .n = n, .block_size = block_size, .first_block = f, .last_block = l,
 			.slots = slots, .slot_stride = stride, .csize = csize };
-		pthread_create(&tid[t], NULL, mt_compress_worker, &jobs[t]);
+		/* a thread that cannot be created (thread / pid limits of the container): its range runs here */
+		created[t] = pthread_create(&tid[t], NULL, mt_compress_worker, &jobs[t]) == 0;
+		if (!created[t])
+			mt_compress_worker(&jobs[t]);
 		started++;
 	}
 	for (int t = 0; t < started; t++)
-		pthread_join(tid[t], NULL);
+		if (created[t])
+			pthread_join(tid[t], NULL);
 	uint8_t *op = dst + oracle_write_header(dst, (uint32_t)n, block_size);
 	for (uint64_t b = 0; b < nblocks; b++) {
 		memcpy(op, slots + b * stride, csize[b]);
@@ -552,6 +557,7 @@ int oracle_decompress_mt(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t 
 	if (nthreads > 256)
 		nthreads = 256;
 	pthread_t tid[256];
+	unsigned char created[256];
 	struct mt_job jobs[256];
 	uint64_t per = (nblocks + nthreads - 1) / nthreads;
 	int started = 0;
@@ -563,12 +569,15 @@ int oracle_decompress_mt(const uint8_t *src, uint64_t n, uint8_t *out, uint64_t 
 			l = nblocks;
 		jobs[t] = (struct mt_job){ .src = src, .n = n, .block_size = bs, .first_block = f, .last_block = l,
 			.offsets = offsets, .out = out, .out_len = total };
-		pthread_create(&tid[t], NULL, mt_decompress_worker, &jobs[t]);
+		created[t] = pthread_create(&tid[t], NULL, mt_decompress_worker, &jobs[t]) == 0;
+		if (!created[t])
+			mt_decompress_worker(&jobs[t]);
 		started++;
 	}
 	int status = ORACLE_OK;
 	for (int t = 0; t < started; t++) {
-		pthread_join(tid[t], NULL);
+		if (created[t])
+			pthread_join(tid[t], NULL);
 		if (jobs[t].status != ORACLE_OK)
 			status = jobs[t].status;
 	}

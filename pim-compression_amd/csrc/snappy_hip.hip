@@ -22,6 +22,7 @@
 
 #include "../../include/snappy_hip.h"
 #include "shard_devices.hpp"
+#include "launch_shape.hpp"
 #include "snappy_kernels.hpp"
 
 namespace {
@@ -111,9 +112,6 @@ constexpr int kDefaultK1Form = 2;       // bulk form for the global-table kernel
 constexpr int kDefaultK1Filter = 1;     // with the LDS slot filter
 constexpr int kDefaultLdsHeadStart = 6; // ~20 us for the LDS-table workgroups to be placed before the global-table kernel starts
 constexpr int kDefaultK1FormLds = 2;    // bulk form for the LDS-table kernel
-constexpr int kDefaultLdsWaves = 768;   // block sizes above 8 KiB: 3 LDS-table wavefronts per CU (3 x 33 KiB) beside 20 global-table ones (3 KiB each: filter + duplicate test)
-constexpr uint32_t kGlobalTableWaves = 256 * 32;   // one wavefront slot per SIMD wave slot of the chip
-constexpr uint32_t kCus = 256, kLdsPerCu = 160u << 10, kWaveSlotsPerCu = 32;
 constexpr int kDefaultGtCache = 512;    // SNAPPY_HIP_GT_CACHE: slots of the write-back cache in LDS in front of the global table, for blocks with full-size hash tables; 0 = none (the ablation build also has 256 and 1024)
 constexpr int kDefaultK1Stream = 1;     // SNAPPY_HIP_K1_STREAM: bit 0 = stream form (snappy_k1_stream.hpp) for the LDS-table kernel (default: +2 % in the mix), bit 1 = for the global-table kernel (default with the slot cache: +3 % there, -2 % without), (ablation build: bit 2 = duo form, two wavefronts per LDS-table block)
 [[maybe_unused]] constexpr int kDefaultPairPerCu = 0;    // two-wavefront LDS-table workgroups per CU beside the global-table wavefronts (0 = round 1's one-wavefront LDS-table kernel)
@@ -256,14 +254,31 @@ int env_int(const char* name, int fallback)
     return (v && *v) ? atoi(v) : fallback;
 }
 
-// LDS-table wavefronts per CU of the default K1 launch for a block size (occupancy follows the table the
-// block size needs).  A wavefront holds 2 x table_entries_for(block_size) bytes of table + 1 KiB of duplicate-slot scratch:
-// 33 KiB from -b 16384 up -- there the measured optimum is 3 per CU beside 20 global-table wavefronts -- but 17 KiB at
-// -b 8192, 9 KiB at -b 4096, ...: then as many as the 160 KiB hold (at most 28, leaving wave slots for the global-table
-// form to mop up), since an LDS-table wavefront costs no table traffic at all.
-// LDS is handed out in blocks; the block size of gfx950 is not documented in the guides of this repo, so budgets round
-// every allocation up to 1 KiB (a multiple of every granule CDNA parts have used)
-uint32_t lds_alloc_bytes(uint32_t bytes) { return (bytes + 1023u) & ~1023u; }
+// The shape of the current device -- compute units, LDS per CU, wavefront slots per CU -- read once per device.  Every launch
+// and the hash-table scratch are sized from it (csrc/launch_shape.hpp), so a partition of the chip (CPX / NPS modes: 32 CUs
+// per logical device) gets grids of its own size.  Falls back to a whole MI355X if the runtime cannot be asked.
+launch_shape::DeviceShape device_shape()
+{
+    static std::mutex m;
+    static launch_shape::DeviceShape shapes[64];
+    static bool known[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return launch_shape::DeviceShape();
+    std::lock_guard<std::mutex> lock(m);
+    if (!known[dev]) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 && p.maxSharedMemoryPerMultiProcessor >= (32u << 10) &&
+            p.maxThreadsPerMultiProcessor >= 64) {
+            shapes[dev].cus = (uint32_t)p.multiProcessorCount;
+            shapes[dev].lds_per_cu = (uint32_t)p.maxSharedMemoryPerMultiProcessor;
+            shapes[dev].wave_slots_per_cu = (uint32_t)p.maxThreadsPerMultiProcessor / 64u;
+        }
+        known[dev] = true;
+    }
+    return shapes[dev];
+}
+
+using launch_shape::lds_alloc_bytes;
 
 // K1's defaults depend on the block size: blocks of more than 8 KiB have the full 16384-slot table, whose global-table form
 // runs at the HBM's random-access rate; there the slot cache and the stream form pay (profiles/r03_gt_cache_block_size_sweep.txt)
@@ -291,16 +306,19 @@ int k1_stream_forms(uint32_t block_size)
 #endif
 }
 
+// dynamic LDS of one LDS-table workgroup of the product's launch at this block size
+uint32_t lds_table_wave_bytes(uint32_t block_size)
+{
+    return (k1_stream_forms(block_size) & 1) ? snappy_hip::lds_table_stream_lds_bytes(block_size)
+                                             : snappy_hip::lds_table_kernel_lds_bytes(block_size, true);
+}
+
 uint32_t default_lds_waves_per_cu(uint32_t block_size)
 {
-    if (gt_cache_slots(block_size)) return 1;    // beside cached global-table wavefronts: one LDS-table wavefront per CU
-    const uint32_t per_wave = lds_alloc_bytes(k1_stream_forms(block_size) & 1
-                                                  ? snappy_hip::lds_table_stream_lds_bytes(block_size)
-                                                  : snappy_hip::lds_table_kernel_lds_bytes(block_size, true));
-    if (per_wave > (24u << 10)) return kDefaultLdsWaves / 256;
-    // small tables: as many LDS-table wavefronts as fit beside at least 8 global-table wavefronts per CU (4 KiB each at
-    // most), which mop up what the LDS-table ones leave; at most 24 of the 32 wave slots
-    return std::min<uint32_t>(24u, ((160u << 10) - 8u * (4u << 10)) / per_wave);
+    launch_shape::K1Knobs k;
+    k.cached_global_table = gt_cache_slots(block_size) != 0;
+    k.lds_wave_bytes = lds_table_wave_bytes(block_size);
+    return launch_shape::default_lds_waves_per_cu(device_shape(), k);
 }
 
 // Number of shards the drop-in pair splits a file into: SNAPPY_HIP_NUM_GPUS (default: every visible device).
@@ -427,6 +445,16 @@ int k1_forms_from_env(K1Forms* f)
         if (getenv(name))
             return fail(SNAPPY_HIP_ERR_ARG, std::string(name) + " selects an ablation kernel; this library was built without them "
                                                                 "(python tools/build_ablation.py builds libsnappy_hip_ablation.so)");
+    // values of the product's own knobs that only the ablation build implements are refused too, not remapped: a sweep run
+    // against this library by mistake must not produce numbers labelled with a configuration that never ran
+    if (const char* v = getenv("SNAPPY_HIP_GT_CACHE"))
+        if (*v && atoi(v) != 0 && atoi(v) != 512)
+            return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_GT_CACHE: this library has the slot cache with 512 slots or none (0); other sizes "
+                                            "are in libsnappy_hip_ablation.so (python tools/build_ablation.py)");
+    if (const char* v = getenv("SNAPPY_HIP_K1_STREAM"))
+        if (*v && (atoi(v) & ~3))
+            return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_K1_STREAM: bits 0 and 1 select the stream form per kernel; bit 2 (duo form) is in "
+                                            "libsnappy_hip_ablation.so only (python tools/build_ablation.py)");
     (void)f;
 #endif
     return 0;
@@ -589,20 +617,21 @@ int snappy_hip_debug_prof(unsigned long long* out, int reset)
 uint32_t snappy_hip_k1_lds_waves_per_cu(uint32_t block_size)
 {
     if (!block_size_ok(block_size)) return 0;
+    [[maybe_unused]] const launch_shape::DeviceShape shape = device_shape();
 #ifdef SNAPPY_ABLATION
     if (const int pair = env_int("SNAPPY_HIP_PAIR_PER_CU", env_int("SNAPPY_HIP_LDS_WAVES", -1) >= 0 ? 0 : kDefaultPairPerCu)) {
         const uint32_t pair_lds = (snappy_hip::pair_lds_bytes(block_size) + 1023u) & ~1023u;
-        return snappy_hip::kPairWaves * std::min<uint32_t>({(uint32_t)pair, kWaveSlotsPerCu / snappy_hip::kPairWaves, kLdsPerCu / pair_lds});
+        return snappy_hip::kPairWaves * std::min<uint32_t>({(uint32_t)pair, shape.wave_slots_per_cu / snappy_hip::kPairWaves, shape.lds_per_cu / pair_lds});
     }
 #endif
     const int forced = env_int("SNAPPY_HIP_LDS_WAVES", -1);
-    return forced >= 0 ? ((uint32_t)forced + kCus - 1) / kCus : default_lds_waves_per_cu(block_size);
+    return forced >= 0 ? ((uint32_t)forced + shape.cus - 1) / shape.cus : default_lds_waves_per_cu(block_size);
 }
 
 uint64_t snappy_hip_compress_scratch_bytes(void)
 {
-    // 256-byte header (work counter) + one 64 KiB tagged hash table per resident wavefront (256 CUs x 32 waves)
-    return 256 + (uint64_t)kGlobalTableWaves * snappy_hip::kMaxTableEntries * sizeof(uint32_t);
+    // 256-byte header (work counter) + one 64 KiB hash table per wavefront slot of the CURRENT device (MI355X: 256 CUs x 32)
+    return launch_shape::compress_scratch_bytes(device_shape());
 }
 
 // K1 over a batch of containers (count >= 1, every container non-empty and validated by the callers below)
@@ -619,22 +648,23 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
     K1Forms forms;
     if (int rc = k1_forms_from_env(&forms)) return rc;
     hipStream_t st = (hipStream_t)stream;
+    const launch_shape::DeviceShape shape = device_shape();
+    const bool scratch_usable = d_scratch && scratch_bytes >= 256 && !((uintptr_t)d_scratch & 255);
     // A small input -- every block can have an LDS-table wavefront at once, at most one per SIMD -- goes to the LDS-table
     // kernel alone: its wavefronts run the stream form with nothing else on their SIMD (dickens_like, 312 blocks: K1 1.27 ->
     // 1.05 ms, profiles/r03_small_inputs.txt); with more blocks than that a second round would follow, and the global-table
     // kernel's 32 wave slots per CU win.
     if (variant == kVariantGlobalTable && !getenv("SNAPPY_HIP_COMPRESS_VARIANT") && !getenv("SNAPPY_HIP_LDS_WAVES") &&
-        (k1_stream_forms(block_size) & 1)) {
-        const uint32_t per_cu = std::min<uint32_t>(4u, kLdsPerCu / lds_alloc_bytes(snappy_hip::lds_table_stream_lds_bytes(block_size)));
-        if (nb <= (uint64_t)per_cu * kCus) variant = kVariantLdsTable;
-    }
+        (k1_stream_forms(block_size) & 1) &&
+        launch_shape::small_input_takes_lds_kernel_alone(shape, snappy_hip::lds_table_stream_lds_bytes(block_size), nb))
+        variant = kVariantLdsTable;
 #ifdef SNAPPY_ABLATION
     if (variant == kVariantOracle) {     // ceiling experiment (csrc/ablation/k1_oracle_table.hpp): the table answered from host-made records
         if (w.count != 1 || !g_oracle_records || !d_scratch)
             return fail(SNAPPY_HIP_ERR_ARG, "variant 6 takes one container, a scratch and snappy_hip_debug_set_oracle_records()");
         uint32_t* counter = static_cast<uint32_t*>(d_scratch);
         HIP_TRY(hipMemsetAsync(counter, 0, 32, st));
-        const uint32_t waves = (uint32_t)std::min<uint64_t>(nb, (uint64_t)env_int("SNAPPY_HIP_GT_WAVES", 20 * 256));
+        const uint32_t waves = (uint32_t)std::min<uint64_t>(nb, (uint64_t)env_int("SNAPPY_HIP_GT_WAVES", (int)(20 * shape.cus)));
         hipLaunchKernelGGL(snappy_hip::compress_blocks_oracle_kernel, dim3(waves), dim3(64), 0, st, w, block_size, slot_stride,
                            g_oracle_records, counter);
         HIP_TRY(hipGetLastError());
@@ -651,7 +681,7 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
             // 4 blocks per wavefront (16-lane groups); its tables are allocated lazily by the library
             static thread_local uint32_t* group_tables = nullptr;
             static thread_local uint64_t group_table_slots = 0;
-            const uint32_t waves = (uint32_t)env_int("SNAPPY_HIP_GROUP_WAVES", kGlobalTableWaves);
+            const uint32_t waves = (uint32_t)env_int("SNAPPY_HIP_GROUP_WAVES", (int)shape.wave_slots());
             const uint64_t want_groups = std::min<uint64_t>((uint64_t)waves * 4, (nb + 3) / 4 * 4);
             const uint32_t g = (uint32_t)((want_groups + 3) / 4);
             if (group_table_slots < (uint64_t)g * 4) {
@@ -687,11 +717,13 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
     if (variant == kVariantLdsTable) {
         launch_lds_table_kernel(forms, (uint32_t)nb, st, w, block_size, slot_stride, (uint32_t*)nullptr);
         HIP_TRY(hipGetLastError());
+        // the statistics word of the scratch (include/snappy_hip.h): every block of this launch had an LDS-table wavefront
+        if (scratch_usable) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(static_cast<uint32_t*>(d_scratch) + 4), (int)nb, 1, st));
         return SNAPPY_HIP_OK;
     }
 
     // ---- the default: persistent grids, blocks handed out by an atomic counter kept in the first bytes of the scratch ----
-    // Wave budget per CU (256 CUs, 32 wave slots, 160 KiB of LDS each): a global-table wavefront holds the duplicate test
+    // Wave budget per CU (MI355X: 256 CUs, 32 wave slots, 160 KiB of LDS each; device_shape()): a global-table wavefront holds the duplicate test
     // (1 KiB) and the slot filter (2 KiB) in LDS and its tagged table in the scratch; the wavefronts whose table lives in
     // LDS are sized by the block length.  SNAPPY_HIP_GT_WAVES overrides the number of global-table wavefronts
     // (with SNAPPY_HIP_LDS_WAVES / round 1's launch: the TOTAL of both kinds).
@@ -725,14 +757,14 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
         // block_size) bytes + 4 KiB of scratch + the token each.  What is left of the CU's LDS and wave slots goes to
         // global-table wavefronts on the same work counter.
         const uint32_t pair_lds = snappy_hip::pair_lds_bytes(block_size);
-        const uint32_t fit = std::min<uint32_t>(kWaveSlotsPerCu / snappy_hip::kPairWaves, kLdsPerCu / ((pair_lds + 1023u) & ~1023u));
+        const uint32_t fit = std::min<uint32_t>(shape.wave_slots_per_cu / snappy_hip::kPairWaves, shape.lds_per_cu / ((pair_lds + 1023u) & ~1023u));
         const uint32_t pair_per_cu = std::min<uint32_t>((uint32_t)pair_req, fit);
-        const uint32_t pair_wgs = (uint32_t)std::min<uint64_t>(nb, (uint64_t)pair_per_cu * kCus);
-        const uint32_t lds_left = kLdsPerCu - pair_per_cu * ((pair_lds + 1023u) & ~1023u);
-        uint32_t g_per_cu = kWaveSlotsPerCu - snappy_hip::kPairWaves * pair_per_cu;
+        const uint32_t pair_wgs = (uint32_t)std::min<uint64_t>(nb, (uint64_t)pair_per_cu * shape.cus);
+        const uint32_t lds_left = shape.lds_per_cu - pair_per_cu * ((pair_lds + 1023u) & ~1023u);
+        uint32_t g_per_cu = shape.wave_slots_per_cu - snappy_hip::kPairWaves * pair_per_cu;
         if (g_wave_bytes) g_per_cu = std::min(g_per_cu, lds_left / g_wave_bytes);
-        uint32_t g_waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", (int)(g_per_cu * kCus));
-        if (g_waves > kGlobalTableWaves) g_waves = kGlobalTableWaves;
+        uint32_t g_waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", (int)(g_per_cu * shape.cus));
+        if (g_waves > shape.wave_slots()) g_waves = shape.wave_slots();
         if (nb <= pair_wgs) g_waves = 0;                      // every block gets a workgroup of its own at once
         const uint32_t g = (uint32_t)std::min<uint64_t>(nb, g_waves);
         auto pair_launch = [&](hipStream_t on) {
@@ -750,36 +782,23 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
 #endif
     // One-wavefront LDS-table workgroups (the default): SNAPPY_HIP_LDS_WAVES of them run concurrently on the helper stream,
     // default_lds_waves_per_cu(block_size) per CU; both kernels draw blocks from the same counter, so the split balances itself.
-    uint32_t lds_waves = (uint32_t)env_int("SNAPPY_HIP_LDS_WAVES", (int)(default_lds_waves_per_cu(block_size) * kCus));
-    if (nb < (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096)) lds_waves = 0;     // small inputs: one kernel is enough
-    uint32_t waves;                                                                        // (decided BEFORE the wave budget below)
-    {
-        const uint32_t lds_per_cu = (lds_waves + kCus - 1) / kCus;
+    launch_shape::K1Knobs knobs;
+    knobs.cached_global_table = gt_cache != 0;
 #ifdef SNAPPY_ABLATION
-        const bool duo = (k1_stream & 4) != 0;
-        const uint32_t duo_bytes = snappy_hip::duo_lds_bytes(block_size);
+    const bool duo = (k1_stream & 4) != 0;
+    knobs.lds_wave_bytes = (duo ? snappy_hip::duo_lds_bytes(block_size)
+                            : (k1_stream & 1) ? snappy_hip::lds_table_stream_lds_bytes(block_size)
+                                              : snappy_hip::lds_table_kernel_lds_bytes(block_size, forms.form_lds != 0)) + forms.extra_lds;
+    knobs.lds_wave_slots = duo ? 2u : 1u;                    // a duo workgroup takes two wave slots
 #else
-        const bool duo = false;
-        const uint32_t duo_bytes = 0;
+    knobs.lds_wave_bytes = lds_table_wave_bytes(block_size);
 #endif
-        const uint32_t lds_wave_bytes = lds_alloc_bytes((duo ? duo_bytes
-                                                         : (k1_stream & 1) ? snappy_hip::lds_table_stream_lds_bytes(block_size)
-                                                                           : snappy_hip::lds_table_kernel_lds_bytes(block_size, forms.form_lds != 0)) +
-                                                        forms.extra_lds);
-        const uint32_t lds_slots = lds_per_cu * (duo ? 2u : 1u);                    // a duo workgroup takes two wave slots
-        uint32_t g_per_cu = kWaveSlotsPerCu > lds_slots ? kWaveSlotsPerCu - lds_slots : 0u;
-        if (g_wave_bytes && lds_per_cu * lds_wave_bytes < kLdsPerCu)
-            g_per_cu = std::min(g_per_cu, (kLdsPerCu - lds_per_cu * lds_wave_bytes) / lds_alloc_bytes(g_wave_bytes));
-        waves = lds_waves + g_per_cu * kCus;
-    }
-    waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", (int)waves);
-    if (waves > kGlobalTableWaves) waves = kGlobalTableWaves;
-    if (lds_waves > waves / 2 && lds_waves < waves) {
-        // small block sizes: most wavefronts have their table in LDS; the global-table form only mops up what is left
-    } else if (lds_waves >= waves) {
-        lds_waves = waves / 2;
-    }
-    const uint32_t g = (uint32_t)std::min<uint64_t>(nb, waves - lds_waves);
+    knobs.gt_wave_bytes = g_wave_bytes;
+    knobs.lds_waves_forced = env_int("SNAPPY_HIP_LDS_WAVES", -1);
+    knobs.waves_forced = env_int("SNAPPY_HIP_GT_WAVES", -1);
+    knobs.hybrid_min_blocks = (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096);     // small inputs: one kernel is enough
+    const launch_shape::K1Launch shape_l = launch_shape::k1_default_launch(shape, knobs, nb);
+    const uint32_t lds_waves = shape_l.lds_waves, g = shape_l.gt_waves;
     if (lds_waves) {
         if (int rc = co_run(g, [&](hipStream_t on) { launch_lds_table_kernel(forms, lds_waves, on, w, block_size, slot_stride, counter); }))
             return rc;
@@ -905,7 +924,8 @@ static int launch_decompress(const snappy_hip::K2Batch& w, uint32_t block_size, 
     WorkCounter wc;
     if (int rc = next_work_counter(&wc, st)) return rc;
     uint32_t* counter = wc.ptr;
-    const uint32_t resident = kGlobalTableWaves;
+    const launch_shape::DeviceShape shape = device_shape();
+    const uint32_t resident = shape.wave_slots();
     const uint32_t k2_cap = (uint32_t)std::max(1, env_int("SNAPPY_HIP_K2_WAVES", (int)resident));   // fewer wavefronts leave slots for a co-running kernel
 #ifdef SNAPPY_ABLATION
     // SNAPPY_HIP_DECOMPRESS_VARIANT: 0 = output window in LDS only, 1 (default) = output window in global memory only,
@@ -1266,8 +1286,9 @@ bool walk_chain(DecompressShard& s, uint64_t upto, const uint8_t* buf, uint64_t 
 int warm_up_device()
 {
     hipFuncAttributes fa;
-    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel<64, 2, 1>)));
-    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_lds_table_kernel<64, 2>)));
+    // (the default K1 launch for blocks of more than 8 KiB: the cached global-table kernel and the LDS-table kernel, stream form)
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_global_table_kernel<64, 3, 1, 512>)));
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::compress_blocks_lds_table_kernel<64, 3>)));
     HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::gather_slots_kernel)));
     HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(snappy_hip::decompress_blocks_kernel)));
     CoRunResources* cr = nullptr;

@@ -402,7 +402,11 @@ struct CachedGlobalTable {
         __builtin_amdgcn_wave_barrier();
         const uint32_t now = cache[idx];
         const bool lost = s && now != mine;
-        // the displaced slot goes out first, then the lanes that lost (one of them may be the displaced slot's new value)
+        // the displaced slot goes out first, then the lanes that lost (one of them may be the displaced slot's new value).
+        // Relied upon: two global_store instructions of ONE wavefront to the same address are performed in issue order, also
+        // when different lanes issue them (vector memory operations of a wavefront complete in order -- global_*, not flat_*:
+        // MI355X_MICROARCH.md; the same guarantee K2's back-references use).  tests/test_abi_symbols.py fails on a flat_*
+        // instruction in any K1 kernel; the wave barrier below only keeps the compiler from reordering the two stores.
         if (s && !lost && old != 0u && (old >> 16) != h + 1u) t[(old >> 16) - 1u] = (uint16_t)old;
         __builtin_amdgcn_wave_barrier();
         if (__ballot(lost)) {                                    // rare: two stores of one call met in a cache word

@@ -550,6 +550,53 @@ def test_compress_without_scratch_uses_lds_table_kernel(shb):
     assert bytes(d_stream[:n].cpu().numpy()) == golden_bytes("world192.snappy")
 
 
+def test_lds_form_block_count_is_written_by_every_launch_shape(shb, monkeypatch):
+    """The statistics word of the scratch (include/snappy_hip.h: blocks compressed by LDS-table wavefronts) must be written by
+    EVERY launch shape -- bench.py prices roofline.traffic with it.  A small input goes to the LDS-table kernel alone
+    (share 1.0); the global-table kernel alone has share 0; the mix lies in between; and a small launch after a large one must
+    not read back the large one's count."""
+    import torch
+    prose = datagen.dickens_like(_prose())                        # 312 blocks: the small-input rule applies
+    big = (prose * 17)[:5000 * 32768]                              # 5000 blocks: the concurrent launch
+    ws = shb.CompressWorkspace(len(big), 32768)
+    d_big, d_small = to_dev(big), to_dev(prose)
+
+    def run(d, n):
+        shb.compress_blocks(d, n, ws)
+        torch.cuda.synchronize()
+        return ws.lds_form_blocks(), shb.num_blocks(n, 32768)
+
+    got, nb = run(d_big, len(big))
+    assert nb == 5000 and 0 < got < nb                            # both kernels took blocks
+    got, nb = run(d_small, len(prose))
+    assert nb == 312 and got == 312                               # every block on an LDS-table wavefront, and not 5000's count
+    monkeypatch.setenv("SNAPPY_HIP_LDS_WAVES", "0")
+    got, nb = run(d_big, len(big))
+    assert got == 0                                               # the global-table kernel alone
+    got, nb = run(d_small, len(prose))                            # (SNAPPY_HIP_LDS_WAVES set: no small-input shortcut)
+    assert got == 0
+    monkeypatch.delenv("SNAPPY_HIP_LDS_WAVES")
+    monkeypatch.setenv("SNAPPY_HIP_COMPRESS_VARIANT", "1")
+    got, nb = run(d_big, len(big))
+    assert got == nb == 5000
+
+
+def test_product_library_refuses_ablation_only_knob_values(shb, monkeypatch):
+    """SNAPPY_HIP_GT_CACHE=256 / 1024 and SNAPPY_HIP_K1_STREAM bit 2 exist in the ablation build only; the product library
+    must fail loudly instead of running its default under that label."""
+    data = golden_bytes("terror2.txt")
+    for name, value in (("SNAPPY_HIP_GT_CACHE", "256"), ("SNAPPY_HIP_GT_CACHE", "1024"), ("SNAPPY_HIP_K1_STREAM", "4"),
+                        ("SNAPPY_HIP_K1_STREAM", "7")):
+        monkeypatch.setenv(name, value)
+        with pytest.raises(shb.SnappyHipError):
+            gpu_compress(shb, data, 32768)
+        monkeypatch.delenv(name)
+    for name, value in (("SNAPPY_HIP_GT_CACHE", "0"), ("SNAPPY_HIP_GT_CACHE", "512"), ("SNAPPY_HIP_K1_STREAM", "3")):
+        monkeypatch.setenv(name, value)
+        assert gpu_compress(shb, data, 32768) == golden_bytes("terror2.snappy")
+        monkeypatch.delenv(name)
+
+
 # ---- BASELINE.json full size: one 1 GiB Silesia-mix container -----------------------------------------
 
 def test_full_size_container_roundtrip_and_oracle(shb):

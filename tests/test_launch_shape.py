@@ -1,0 +1,80 @@
+"""csrc/launch_shape.hpp -- the arithmetic that sizes K1 / K2 launches and the hash-table scratch from the device's shape
+(compute units, LDS per CU, wavefront slots per CU; read with hipGetDeviceProperties in snappy_hip.hip::device_shape()).
+Compiled on the CPU (no HIP): a whole MI355X (256 CUs) must get exactly the launches round 3 measured, and a partition of
+it (CPX / NPS modes: 32 CUs) launches of its own size -- VERDICT r03 item 5."""
+import os
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pim-compression_amd", "csrc")
+
+SRC = r'''
+#include <cstdio>
+#include "launch_shape.hpp"
+using namespace launch_shape;
+#define CHECK(c) do { if (!(c)) { std::printf("line %d: %s\n", __LINE__, #c); return 1; } } while (0)
+int main() {
+    DeviceShape whole;                       // the defaults ARE a whole MI355X
+    CHECK(whole.cus == 256 && whole.lds_per_cu == 160u << 10 && whole.wave_slots_per_cu == 32);
+    DeviceShape part;
+    part.cus = 32;
+    CHECK(whole.wave_slots() == 8192 && part.wave_slots() == 1024 && whole.simds_per_cu() == 4);
+    CHECK(compress_scratch_bytes(whole) == 256 + 8192ull * 65536 && compress_scratch_bytes(part) == 256 + 1024ull * 65536);
+
+    // -b 32768, the product's launch: cached global-table wavefronts (4 KiB + 512 slots = 6 KiB of LDS each) beside ONE
+    // LDS-table wavefront per CU (32 KiB table + 4 KiB of analysis tables)
+    K1Knobs k;
+    k.cached_global_table = true;
+    k.lds_wave_bytes = 2 * lds_table_entries(32768) + 4096;
+    k.gt_wave_bytes = 6144;
+    for (const DeviceShape& d : {whole, part}) {
+        CHECK(default_lds_waves_per_cu(d, k) == 1);
+        const K1Launch l = k1_default_launch(d, k, 262144);
+        CHECK(l.lds_waves == d.cus);                                   // one per CU
+        CHECK(l.gt_waves == 20 * d.cus);                               // (160 - 36) KiB / 6 KiB = 20 per CU
+        CHECK(l.lds_waves + l.gt_waves <= d.wave_slots());
+        const K1Launch few = k1_default_launch(d, k, 1000);            // below SNAPPY_HIP_HYBRID_MIN_BLOCKS: one kernel
+        CHECK(few.lds_waves == 0 && few.gt_waves == std::min(1000u, 26 * d.cus));   // 160 KiB / 6 KiB = 26 per CU requested
+        // the small-input rule: one LDS-table wavefront per SIMD at most
+        CHECK(small_input_takes_lds_kernel_alone(d, k.lds_wave_bytes, 4 * d.cus));
+        CHECK(!small_input_takes_lds_kernel_alone(d, k.lds_wave_bytes, 4 * d.cus + 1));
+        CHECK(k2_launch_waves(d, 262144, 0) == d.wave_slots() && k2_launch_waves(d, 10, 0) == 10 && k2_launch_waves(d, 262144, 512) == 512);
+    }
+    // without the slot cache (round 2's mix): three LDS-table wavefronts per CU beside 3 KiB global-table ones
+    K1Knobs r2;
+    r2.lds_wave_bytes = 2 * lds_table_entries(32768) + 1024;
+    r2.gt_wave_bytes = 3072;
+    CHECK(default_lds_waves_per_cu(whole, r2) == 3);
+    K1Launch l = k1_default_launch(whole, r2, 262144);
+    CHECK(l.lds_waves == 768 && l.gt_waves == 20 * 256);             // (160 - 99) KiB / 3 KiB = 20
+    // small tables (-b 4096: 8 KiB table + 1 KiB): as many as fit beside eight global-table wavefronts, at most 24
+    K1Knobs sm;
+    sm.lds_wave_bytes = 2 * lds_table_entries(4096) + 1024;
+    sm.gt_wave_bytes = 3072;
+    CHECK(lds_table_entries(4096) == 4096 && lds_table_entries(100) == 256 && lds_table_entries(65535) == 16384);
+    CHECK(default_lds_waves_per_cu(whole, sm) == 14);                // (160 - 32) KiB / 9 KiB
+    l = k1_default_launch(whole, sm, 262144);
+    CHECK(l.lds_waves == 14 * 256 && l.gt_waves == 11 * 256);        // (160 - 126) KiB / 3 KiB = 11 <= 32 - 14
+    // overrides: SNAPPY_HIP_LDS_WAVES=0 -> the global-table kernel alone; a forced total is capped at the device's slots
+    K1Knobs f = k;
+    f.lds_waves_forced = 0;
+    l = k1_default_launch(whole, f, 262144);
+    CHECK(l.lds_waves == 0 && l.gt_waves == 26 * 256);               // 160 KiB / 6 KiB (occupancy then limits the residents)
+    f.waves_forced = 100000;
+    CHECK(k1_default_launch(part, f, 262144).gt_waves == part.wave_slots());
+    f.lds_waves_forced = 5000;
+    f.waves_forced = 4096;                                           // more LDS-table wavefronts than the total: halved
+    l = k1_default_launch(whole, f, 262144);
+    CHECK(l.lds_waves == 2048 && l.gt_waves == 2048);
+    std::puts("ok");
+    return 0;
+}
+'''
+
+
+def test_launch_shape_arithmetic_whole_chip_and_partition(tmp_path):
+    src = tmp_path / "t.cpp"
+    src.write_text(SRC)
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", CSRC, str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout
