@@ -13,6 +13,7 @@ uint32).  --scaling strong (default): the 8 containers are dealt 
 --workload dickens_like|mozilla_like|spamfile_like times one file of BASELINE configs[2]/[3] on one GPU instead.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --gpus N --steps K --warmup W          (no launcher: starts its own N ranks, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 """
@@ -44,6 +45,66 @@ def dist_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     return rank, world, local
+
+
+def child_environment(rank, world, port, base=None):
+    """Environment of rank `rank` of a job this script starts itself (`python bench.py --gpus N` without a launcher): what
+    torch.distributed.run would have set, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    return env
+
+
+def launched_by_a_launcher(environ=None):
+    """True under torch.distributed.run (or any launcher that sets the rank environment): then this process IS a rank."""
+    environ = os.environ if environ is None else environ
+    return "WORLD_SIZE" in environ or "RANK" in environ
+
+
+def launch_ranks(world, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher: like the reference's offload entry, which allocates its own N
+    devices (snappy_compress.c:535), start the N ranks here -- one child process per GPU, each a plain `python bench.py` with
+    the rank environment set.  The parent never touches the GPU (no torch.cuda / HIP call is made before this point and none
+    after), nothing re-execs; rank 0's stdout (the ONE JSON line) is relayed, every rank's stderr is inherited, and the exit
+    code is non-zero if any rank's is.  A rank that dies takes the others down (they would wait at a barrier for ever)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    script = os.path.abspath(__file__)
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=child_environment(r, world, port),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
+    out0 = []
+    import threading
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    codes = [None] * world
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for i, p in enumerate(procs):                         # exactly the processes started above, by handle
+                if codes[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[i] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write("".join(out0))
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    return (bad[0] if bad[0] and bad[0] > 0 else 1) if bad else 0
 
 
 def shard_plan(rank, world, containers, scaling="strong"):
@@ -404,6 +465,12 @@ def main():
                          "launches would mix with the batched ones in a rocprofv3 --stats average); the timed path itself is "
                          "still checked bit for bit after the last step")
     args = ap.parse_args()
+
+    # N > 1 without a launcher: start the N ranks from here (before anything touches the GPU) and relay rank 0's line
+    if args.gpus > 1 and not launched_by_a_launcher():
+        if args.workload != "silesia_mix":
+            raise SystemExit("--workload of one file runs on one GPU (its blocks shard inside snappy_compress_gpu, not here)")
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import snappy_hip_binding as shb

@@ -58,3 +58,25 @@ def test_bench_two_ranks_on_one_device():
              env={"SNAPPY_BENCH_BACKEND": "gloo", "SNAPPY_BENCH_SINGLE_DEVICE": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["containers_this_rank"] == 1               # the two containers were dealt one per rank
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no torchrun around it (how the driver runs the N = 1 line) must BE a two-rank job: the
+    parent starts one child per GPU and relays rank 0's line (the reference's entry point allocates its
+    own N devices, snappy_compress.c:535).  Both ranks share this box's one device; gloo carries the control plane."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"SNAPPY_BENCH_BACKEND": "gloo", "SNAPPY_BENCH_SINGLE_DEVICE": "1"})
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--containers", "2", "--container-mib", "64", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["roundtrip_bit_exact"] is True
+    assert d["config"]["containers_this_rank"] == 1
+    # a rank that fails takes the job down with a non-zero exit code instead of hanging the others at a barrier
+    # (SNAPPY_HIP_GT_CACHE=256 is an ablation-only value: the product library refuses the first K1 launch of every rank)
+    bad = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--containers", "2", "--container-mib", "64", "--steps", "1",
+                          "--warmup", "0", "--no-cpu-baseline"], cwd=ROOT, env=dict(env, SNAPPY_HIP_GT_CACHE="256"),
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]

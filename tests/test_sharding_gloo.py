@@ -189,3 +189,19 @@ int main() {
     subprocess.check_call(["g++", "-std=c++17", "-I", csrc, str(src), "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.returncode
+
+
+def test_bench_child_environment_and_launcher_detection():
+    """bench.py --gpus N without a launcher starts its own ranks (bench.launch_ranks); the pieces that need no GPU: the
+    environment each child gets, and when the script considers itself launched already."""
+    import bench
+    base = {"PATH": "/usr/bin", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    envs = [bench.child_environment(r, 4, 29517, base) for r in range(4)]
+    for r, e in enumerate(envs):
+        assert e["RANK"] == e["LOCAL_RANK"] == str(r) and e["WORLD_SIZE"] == e["LOCAL_WORLD_SIZE"] == "4"
+        assert e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29517"
+        assert e["PATH"] == "/usr/bin" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"      # the parent's environment travels
+        assert bench.launched_by_a_launcher(e)                                          # a child never starts children
+    assert base == {"PATH": "/usr/bin", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}              # (not modified in place)
+    assert not bench.launched_by_a_launcher(base)
+    assert bench.launched_by_a_launcher({"WORLD_SIZE": "1"}) and bench.launched_by_a_launcher({"RANK": "0"})
