@@ -60,6 +60,14 @@ struct StreamProf {
 #define PROF_LAP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == (i)) { prof.acc += now_ - prof.last; prof.cnt++; } prof.last = now_; } while (0)
 #define PROF_WAIT() __builtin_amdgcn_s_waitcnt(0)
 #define PROF_FLUSH() do { if (lane < 16) { atomicAdd(&g_prof[lane], prof.acc); atomicAdd(&g_prof[16 + lane], prof.cnt); } } while (0)
+#elif defined(SNAPPY_MARK)
+// -DSNAPPY_MARK (tools/isa_phase_counts.py): the lap points become comments in the assembly, so that the instructions of the
+// stream form can be counted per phase in the .s file.  Not a product build.
+struct StreamProf {};
+#define PROF_START() asm volatile("; PHASE start")
+#define PROF_LAP(i) asm volatile("; PHASE " #i)
+#define PROF_WAIT() ((void)0)
+#define PROF_FLUSH() ((void)0)
 #else
 struct StreamProf {};
 #define PROF_START() ((void)0)

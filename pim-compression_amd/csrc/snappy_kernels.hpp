@@ -17,6 +17,10 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
+#ifdef SNAPPY_EMU
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 namespace snappy_hip {
 
@@ -306,6 +310,27 @@ __device__ __forceinline__ void lds_st32u(lds_bytes_t p, uint32_t v)
 namespace snappy_hip {
 #endif
 
+// Emulator only: aborts when two lanes of one (emulated) store instruction write the same table entry -- on the GPU it is
+// not defined which of them lands last.  All lanes call, between two collectives.
+#ifdef SNAPPY_EMU
+inline uint32_t g_emu_store_index[16][kWave];                    // per emulated workgroup (grids of the emulator are tiny)
+__device__ __forceinline__ void emu_check_distinct_stores(bool stores, uint32_t index, uint32_t lane)
+{
+    uint32_t* mine = g_emu_store_index[blockIdx.x & 15u];
+    mine[lane] = stores ? index : 0xffffffffu;
+    __builtin_amdgcn_wave_barrier();
+    if (stores)
+        for (uint32_t l = 0; l < kWave; ++l)
+            if (l != lane && mine[l] == index) {
+                fprintf(stderr, "emulator: lanes %u and %u store to table entry %u in one instruction\n", lane, l, index);
+                abort();
+            }
+    __builtin_amdgcn_wave_barrier();
+}
+#else
+__device__ __forceinline__ void emu_check_distinct_stores(bool, uint32_t, uint32_t) {}
+#endif
+
 // TaggedGlobalTable behind a one-bit-per-slot "written in this block" filter in LDS (2 KiB per wavefront).  Early in a
 // block most slots still hold the initial entry (candidate position 0, :145 + :346), and the speculative gathers of the
 // look-ahead forms read 64 slots per 64 input bytes -- one random 64-byte HBM line per input byte, which is what bounds
@@ -389,7 +414,13 @@ struct CachedGlobalTable {
     }
     // All lanes call; the lanes in `m` (each its own slot) insert `pos`.  Lanes of one call that share a cache word: one
     // of them gets it (read back, not assumed), the others write through.
-    __device__ __forceinline__ void store_masked(unsigned long long m, uint32_t h, uint32_t pos, uint32_t) const
+    // Round 4 tried ONE LDS atomic exchange per inserting lane instead (the word that comes back is displaced to the global
+    // table): 10 instructions per call instead of ~25, bit-exact once the displaced words of earlier calls and those of the
+    // call's own lanes went out in two store instructions -- in one, the old and the new position of a slot can meet at one
+    // address, and which lands last is not defined (three lanes in a cache word, once per ~1,300 blocks of the benchmark data:
+    // found on the GPU, now caught by emu_check_distinct_stores).  No faster on any workload
+    // (profiles/r04_store_xchg_ab.txt), so the protocol that has three rounds of soak behind it stays.
+    __device__ __forceinline__ void store_masked(unsigned long long m, uint32_t h, uint32_t pos, uint32_t lane) const
     {
         const bool s = __builtin_amdgcn_inverse_ballot_w64(m);
         const uint32_t idx = h & (kSlots - 1u), mine = ((h + 1u) << 16) | (pos & 0xffffu);
@@ -407,10 +438,16 @@ struct CachedGlobalTable {
         // when different lanes issue them (vector memory operations of a wavefront complete in order -- global_*, not flat_*:
         // MI355X_MICROARCH.md; the same guarantee K2's back-references use).  tests/test_abi_symbols.py fails on a flat_*
         // instruction in any K1 kernel; the wave barrier below only keeps the compiler from reordering the two stores.
-        if (s && !lost && old != 0u && (old >> 16) != h + 1u) t[(old >> 16) - 1u] = (uint16_t)old;
+        // Within ONE store instruction no two lanes may share an address (not defined which would land last): the displaced
+        // words belong to distinct cache words, hence distinct slots, and the lanes of `m` have slots of their own; the
+        // emulator checks it (emu_check_distinct_stores).
+        const bool evicts = s && !lost && old != 0u && (old >> 16) != h + 1u;
+        if (evicts) t[(old >> 16) - 1u] = (uint16_t)old;
+        emu_check_distinct_stores(evicts, (old >> 16) - 1u, lane);
         __builtin_amdgcn_wave_barrier();
         if (__ballot(lost)) {                                    // rare: two stores of one call met in a cache word
             if (lost) t[h] = (uint16_t)pos;
+            emu_check_distinct_stores(lost, h, lane);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1703,6 +1740,12 @@ __device__ __forceinline__ void k2_chain_walk(uint32_t advv, uint32_t wlim, uint
 // (starts 0, 3, .. 63) = 1408; rounded up.
 constexpr uint32_t kK2StageBytes = 1536;
 
+// levels of doubling in front of K2's serial chain walk: the walk visits every 2^L-th element
+#ifndef SNAPPY_K2_WALK_LEVELS
+#define SNAPPY_K2_WALK_LEVELS 2
+#endif
+constexpr uint32_t kK2WalkLevels = SNAPPY_K2_WALK_LEVELS;
+
 // One K2 launch can serve several streams (their own block offsets, output and status arrays; one block size): the
 // persistent wavefronts draw GLOBAL block numbers and map them to (stream, block), so a batch has one tail instead of one
 // per stream -- the decode-side twin of K1Batch.  Passed by value; the kernel argument segment is read with scalar loads.
@@ -1804,20 +1847,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
                 const uint32_t advv = __builtin_amdgcn_inverse_ballot_w64(REJ) ? 64u : e_consumed;
                 uint32_t s = cp - g;
                 unsigned long long E = 0;
-                // The serial walk visits every SECOND element: adv2 = this element's size plus its successor's (one ds_bpermute;
-                // nothing added when the successor starts beyond the window, so the walk still ends on the first start at or
-                // beyond wlim).  The elements in between are filled in afterwards, all at once: every visited lane whose
-                // successor starts inside the window pushes a 1 to it (ds_permute, the forward form); the other lanes push to
-                // lane 0, which cannot be anybody's successor.
+                // The serial walk visits every 2^L-th element (L = kK2WalkLevels): jump[k] = the compressed bytes of this element
+                // and its next 2^k - 1 successors, built by doubling (jump[k] = jump[k-1] + jump[k-1] of the start 2^(k-1)
+                // elements ahead: one ds_bpermute per level; nothing is added for a start beyond the window, so the walk still
+                // ends on the first start at or beyond wlim).  The starts in between are filled in afterwards, level by level:
+                // every lane of E whose 2^k-th successor starts inside the window pushes a 1 to it (ds_permute, the forward
+                // form; lanes of E lie on one chain, so their targets are distinct); the other lanes push to lane 0, which
+                // cannot be anybody's successor.
                 {
-                    const uint32_t nxt = lane + advv;
-                    const uint32_t a_n = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxt << 2), (int)advv);
-                    const bool has2 = nxt < wlim;
-                    const uint32_t adv2 = advv + (has2 ? a_n : 0u);
-                    k2_chain_walk(adv2, wlim, s, E);
-                    const bool pusher = __builtin_amdgcn_inverse_ballot_w64(E) && has2;
-                    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(pusher ? nxt << 2 : 0u), pusher ? 1 : 0);
-                    E |= __ballot(got != 0) & ~1ull;
+                    uint32_t jump[kK2WalkLevels + 1], tgt[kK2WalkLevels + 1];
+                    jump[0] = advv;
+                    tgt[0] = lane + advv;
+#pragma unroll
+                    for (uint32_t k = 1; k <= kK2WalkLevels; ++k) {
+                        const uint32_t a_n = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(tgt[k - 1] << 2), (int)jump[k - 1]);
+                        jump[k] = jump[k - 1] + (tgt[k - 1] < wlim ? a_n : 0u);
+                        tgt[k] = lane + jump[k];
+                    }
+                    k2_chain_walk(jump[kK2WalkLevels], wlim, s, E);
+#pragma unroll
+                    for (uint32_t k = kK2WalkLevels; k-- > 0;) {
+                        const bool pusher = __builtin_amdgcn_inverse_ballot_w64(E) && tgt[k] < wlim;
+                        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(pusher ? tgt[k] << 2 : 0u), pusher ? 1 : 0);
+                        E |= __ballot(got != 0) & ~1ull;
+                    }
                 }
                 if (E & REJ) {                                           // an element predecode rejected
                     st = kBlockInvalid;

@@ -12,14 +12,17 @@ _LIB = None
 
 def build():
     src = os.path.join(HERE, "emu", "emu_runtime.cpp")
-    out = os.path.join(HERE, "emu", "libsnappy_emu.so")
+    # EMU_CXXFLAGS (e.g. -DSNAPPY_K2_WALK_LEVELS=2): extra flags for an experimental build of the kernels, kept in a library of its own
+    extra = os.environ.get("EMU_CXXFLAGS", "").split()
+    tag = ("_" + "".join(c if c.isalnum() else "_" for c in "".join(extra))) if extra else ""
+    out = os.path.join(HERE, "emu", f"libsnappy_emu{tag}.so")
     csrc = os.path.join(ROOT, "pim-compression_amd", "csrc")
     deps = [src, os.path.join(HERE, "emu", "hip", "hip_runtime.h"), os.path.join(csrc, "snappy_kernels.hpp"),
             os.path.join(csrc, "snappy_k1_stream.hpp")] + [os.path.join(csrc, "ablation", f) for f in os.listdir(os.path.join(csrc, "ablation"))]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         # -DSNAPPY_ABLATION: the emulator also compiles the non-default kernel forms under csrc/ablation/
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DSNAPPY_ABLATION", "-I" + os.path.join(HERE, "emu"),
-                               "-I" + os.path.join(ROOT, "pim-compression_amd", "csrc"), src, "-o", out])
+                               "-I" + os.path.join(ROOT, "pim-compression_amd", "csrc")] + extra + [src, "-o", out])
     return out
 
 

@@ -234,3 +234,17 @@ def test_emulated_duo_form_under_shuffled_wave_schedules(seed):
     here = os.path.dirname(os.path.abspath(__file__))
     out = subprocess.run([sys.executable, "-c", _DUO_STRESS, here, str(seed)], env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_emulated_slot_cache_block_with_three_lanes_in_one_cache_word():
+    """tests/fixtures/mix_block_three_lanes_in_a_cache_word.bin: block 392 of the benchmark container.  In one commit of its
+    parse three lanes meet in one word of the slot cache while the word's old content belongs to the slot one of them inserts
+    -- the case in which round 4's one-exchange store protocol put a slot's old and new position into ONE store instruction
+    (2 bytes differed on the GPU; the emulator now aborts on two lanes of a table-store instruction sharing an address,
+    snappy_kernels.hpp: emu_check_distinct_stores).  Every cached-table form must produce the oracle's bytes."""
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures", "mix_block_three_lanes_in_a_cache_word.bin"), "rb") as f:
+        data = f.read()
+    assert len(data) == 32768
+    ref = oracle.compress(data, 32768)
+    for cv in (43503, 42503, 53503):
+        assert emu.compress(data, 32768, variant=cv) == ref, cv

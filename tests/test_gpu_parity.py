@@ -581,6 +581,18 @@ def test_lds_form_block_count_is_written_by_every_launch_shape(shb, monkeypatch)
     assert got == nb == 5000
 
 
+def test_block_with_three_lanes_in_one_slot_cache_word(shb, monkeypatch):
+    """The benchmark block in which three lanes of one commit meet in one word of the slot cache (see the emulator test of the
+    same fixture): the cached global-table kernel alone, both forms, must produce the oracle's bytes."""
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures", "mix_block_three_lanes_in_a_cache_word.bin"), "rb") as f:
+        data = f.read() * 3
+    ref = oracle.compress(data, 32768)
+    monkeypatch.setenv("SNAPPY_HIP_LDS_WAVES", "0")
+    for stream_form in ("3", "1"):
+        monkeypatch.setenv("SNAPPY_HIP_K1_STREAM", stream_form)
+        assert gpu_compress(shb, data, 32768) == ref, stream_form
+
+
 def test_product_library_refuses_ablation_only_knob_values(shb, monkeypatch):
     """SNAPPY_HIP_GT_CACHE=256 / 1024 and SNAPPY_HIP_K1_STREAM bit 2 exist in the ablation build only; the product library
     must fail loudly instead of running its default under that label."""
