@@ -36,7 +36,7 @@ inline uint64_t compress_scratch_bytes(const DeviceShape& d) { return 256 + (uin
 // what the caller has decided about the kernels (block-size dependent defaults and environment overrides, snappy_hip.hip)
 struct K1Knobs {
     uint32_t lds_wave_bytes = 0;          // dynamic LDS of one LDS-table workgroup (table + scratch), not yet rounded
-    uint32_t lds_wave_slots = 1;          // wavefront slots one LDS-table workgroup takes (2 for the ablation build's duo form)
+    uint32_t lds_wave_slots = 1;          // wavefront slots one LDS-table workgroup takes
     uint32_t gt_wave_bytes = 0;           // static LDS of one global-table wavefront (filter, slot cache, duplicate test)
     bool cached_global_table = false;     // the slot cache is in front of the global table (blocks of more than 8 KiB)
     int lds_waves_forced = -1;            // SNAPPY_HIP_LDS_WAVES (LDS-table wavefronts of the launch), -1 = default
@@ -57,12 +57,15 @@ inline uint32_t default_lds_waves_per_cu(const DeviceShape& d, const K1Knobs& k)
     return std::min<uint32_t>(d.wave_slots_per_cu * 3u / 4u, room / std::max(1u, per_wave));
 }
 
-// A small input -- every block can have an LDS-table wavefront at once, at most one per SIMD -- goes to the LDS-table kernel
-// alone: its wavefronts run the stream form with nothing else on their SIMD (measured for full-size tables: 312 blocks,
-// K1 1.27 -> 1.05 ms, profiles/r03_small_inputs.txt; r04_small_inputs.txt has the points around the cut-over).
+// A small input -- every block can have an LDS-table wavefront at once -- goes to the LDS-table kernel alone: its wavefronts
+// run the stream form with (almost) nothing else on their SIMD.  Measured on both sides of the cut-over
+// (profiles/r04_small_inputs_threshold.txt): 32 KiB blocks (36 KiB of LDS per wavefront: four per CU, one per SIMD) -- 1,024
+// blocks 1.09 ms against 1.59 ms for the global-table kernel alone, 1,100 blocks 2.08 against 1.74; 8 KiB blocks (20 KiB: eight
+// per CU, two per SIMD) -- 2,048 blocks 0.39 against 0.47 ms, 2,571 blocks 0.65 against 0.54.  So: as many blocks as LDS-table
+// wavefronts fit at once, at most two per SIMD.
 inline bool small_input_takes_lds_kernel_alone(const DeviceShape& d, uint32_t stream_lds_wave_bytes, uint64_t num_blocks)
 {
-    const uint32_t per_cu = std::min<uint32_t>(d.simds_per_cu(), d.lds_per_cu / std::max(1u, lds_alloc_bytes(stream_lds_wave_bytes)));
+    const uint32_t per_cu = std::min<uint32_t>(2u * d.simds_per_cu(), d.lds_per_cu / std::max(1u, lds_alloc_bytes(stream_lds_wave_bytes)));
     return num_blocks <= (uint64_t)per_cu * d.cus;
 }
 

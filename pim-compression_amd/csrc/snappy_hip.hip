@@ -102,19 +102,16 @@ int for_each_device(int count, const std::function<int(int)>& fn)
 
 constexpr int kVariantLdsTable = 1, kVariantGlobalTable = 3;
 #ifdef SNAPPY_ABLATION
-constexpr int kVariantLanePerBlock = 4, kVariantGroup = 5, kVariantOracle = 6;
+// The ablation build (tools/build_ablation.py) = the product + ONE experiment kernel: K1 with its hash table answered from
+// host-made records (csrc/ablation/k1_oracle_table.hpp, gate (b) of round 4's two-pass question).  The kernel forms of rounds
+// 1-3 that do not ship (windowed / masked parses, unfiltered and class-filtered tables, lane-per-block, four blocks per
+// wavefront, two-wavefront LDS forms, K2's element loop) were removed in round 4; they are in the history (profiles/HISTORY.md).
+constexpr int kVariantOracle = 6;
 const uint32_t* g_oracle_records = nullptr;    // device array, one u32 per input position (tools/gate_b_ceiling.py)
 #endif
-constexpr int kDefaultDecompressVariant = 1;   // the concurrent LDS+global form (2) measured no faster for K2
-constexpr int kDefaultK1Ahead = 64;     // look-ahead of the global-table form (64 = the whole cursor window)
-constexpr int kDefaultK1AheadLds = 64;  // look-ahead of the LDS-table form
-constexpr int kDefaultK1Form = 2;       // bulk form for the global-table kernel
-constexpr int kDefaultK1Filter = 1;     // with the LDS slot filter
 constexpr int kDefaultLdsHeadStart = 6; // ~20 us for the LDS-table workgroups to be placed before the global-table kernel starts
-constexpr int kDefaultK1FormLds = 2;    // bulk form for the LDS-table kernel
-constexpr int kDefaultGtCache = 512;    // SNAPPY_HIP_GT_CACHE: slots of the write-back cache in LDS in front of the global table, for blocks with full-size hash tables; 0 = none (the ablation build also has 256 and 1024)
-constexpr int kDefaultK1Stream = 1;     // SNAPPY_HIP_K1_STREAM: bit 0 = stream form (snappy_k1_stream.hpp) for the LDS-table kernel (default: +2 % in the mix), bit 1 = for the global-table kernel (default with the slot cache: +3 % there, -2 % without), (ablation build: bit 2 = duo form, two wavefronts per LDS-table block)
-[[maybe_unused]] constexpr int kDefaultPairPerCu = 0;    // two-wavefront LDS-table workgroups per CU beside the global-table wavefronts (0 = round 1's one-wavefront LDS-table kernel)
+constexpr int kDefaultGtCache = 512;    // SNAPPY_HIP_GT_CACHE: slots of the write-back cache in LDS in front of the global table, for blocks with full-size hash tables; 0 = none
+constexpr int kDefaultK1Stream = 1;     // SNAPPY_HIP_K1_STREAM: bit 0 = stream form (snappy_k1_stream.hpp) for the LDS-table kernel (default: +2 % in the mix), bit 1 = for the global-table kernel (default with the slot cache: +3 % there, -2 % without)
 
 // Work counters for persistent kernels: a ring in the code object's own global memory (one copy per device), so launches
 // need no allocation.  Each launch takes the next slot of its device's ring, zeroes it on its stream and leaves an event
@@ -284,26 +281,11 @@ using launch_shape::lds_alloc_bytes;
 // runs at the HBM's random-access rate; there the slot cache and the stream form pay (profiles/r03_gt_cache_block_size_sweep.txt)
 int gt_cache_slots(uint32_t block_size)
 {
-#ifdef SNAPPY_ABLATION
-    const int def = 0;
-#else
-    const int def = block_size > 8192u ? kDefaultGtCache : 0;
-#endif
-    const int v = env_int("SNAPPY_HIP_GT_CACHE", def);
-#ifdef SNAPPY_ABLATION
-    return (v == 256 || v == 512 || v == 1024) ? v : 0;          // other sizes: sweeps (tools/gt_cache_sweep.sh)
-#else
-    return v ? 512 : 0;
-#endif
+    return env_int("SNAPPY_HIP_GT_CACHE", block_size > 8192u ? kDefaultGtCache : 0) ? 512 : 0;    // (values other than 0 / 512 are refused: check_knobs)
 }
 int k1_stream_forms(uint32_t block_size)
 {
-#ifdef SNAPPY_ABLATION
-    (void)block_size;
-    return env_int("SNAPPY_HIP_K1_STREAM", 0);
-#else
     return env_int("SNAPPY_HIP_K1_STREAM", kDefaultK1Stream | (gt_cache_slots(block_size) ? 2 : 0));
-#endif
 }
 
 // dynamic LDS of one LDS-table workgroup of the product's launch at this block size
@@ -356,171 +338,56 @@ struct CallerDevice {
     }
 };
 
-// K1 launchers.  The product library holds ONE K1 pair -- the bulk parse with look-ahead 64, as the global-table kernel
-// behind the LDS slot filter and as the LDS-table kernel -- plus the two-wavefront LDS form.  The other forms of round 1
-// (windowed / masked parses, look-ahead widths, unfiltered and class-filtered tables, lane-per-block and group kernels)
-// are ablation code under csrc/ablation/, compiled only with -DSNAPPY_ABLATION (tools/build_ablation.py).
-#ifdef SNAPPY_ABLATION
-// SNAPPY_HIP_K1_AHEAD[_LDS] = look-ahead width of the speculative table reads (0 = serial probes only);
-// SNAPPY_HIP_K1_FORM[_LDS] = 1 selects the masked form (lane-mask resolution of the probes), 2 the bulk form
-// (per-segment table commit and emission); both need a look-ahead >= 16.
-template <uint32_t kAhead, int kForm>
-void launch_k1_global(uint32_t grid, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size, uint32_t slot_stride,
-                      uint32_t* tables, uint32_t* counter)
-{
-    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<kAhead, kForm>), dim3(grid), dim3(64), 0, st, w, block_size,
-                       slot_stride, tables, counter);
-}
-// same, with the LDS "slot written" filter in front of the table (SNAPPY_HIP_K1_FILTER=1)
-template <uint32_t kAhead, int kForm>
-void launch_k1_global_filtered(uint32_t grid, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size,
-                               uint32_t slot_stride, uint32_t* tables, uint32_t* counter)
-{
-    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<kAhead, kForm, 1>), dim3(grid), dim3(64), 0, st, w,
-                       block_size, slot_stride, tables, counter);
-}
-inline void launch_k1_global_class_filtered(uint32_t grid, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size,
-                                            uint32_t slot_stride, uint32_t* tables, uint32_t* counter)
-{
-    hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 2, 2>), dim3(grid), dim3(64), 0, st, w, block_size,
-                       slot_stride, tables, counter);
-}
-#define SNAPPY_K1_DISPATCH_FILTERED(ahead, form, ...)                                   \
-    do {                                                                                \
-        if ((form) == 2) {                                                              \
-            if ((ahead) >= 64) launch_k1_global_filtered<64, 2>(__VA_ARGS__);           \
-            else launch_k1_global_filtered<32, 2>(__VA_ARGS__);                         \
-        } else if ((form) == 1) {                                                       \
-            launch_k1_global_filtered<64, 1>(__VA_ARGS__);                              \
-        } else {                                                                        \
-            if ((ahead) >= 64) launch_k1_global_filtered<64, 0>(__VA_ARGS__);           \
-            else launch_k1_global_filtered<16, 0>(__VA_ARGS__);                         \
-        }                                                                               \
-    } while (0)
-template <uint32_t kAhead, int kForm>
-void launch_k1_lds(uint32_t grid, uint32_t lds, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size,
-                   uint32_t slot_stride, uint32_t* counter)
-{
-    hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<kAhead, kForm>), dim3(grid), dim3(64),
-                       snappy_hip::lds_table_kernel_lds_bytes(block_size, kForm != 0) + lds, st, w, block_size, slot_stride, counter);
-}
-#define SNAPPY_K1_DISPATCH(fn, ahead, form, ...)                \
-    do {                                                        \
-        if ((form) == 2) {                                      \
-            if ((ahead) >= 64) fn<64, 2>(__VA_ARGS__);          \
-            else fn<32, 2>(__VA_ARGS__);                        \
-        } else if ((form) == 1) {                               \
-            if ((ahead) >= 64) fn<64, 1>(__VA_ARGS__);          \
-            else fn<32, 1>(__VA_ARGS__);                        \
-        } else {                                                \
-            if ((ahead) >= 64) fn<64, 0>(__VA_ARGS__);          \
-            else if ((ahead) >= 32) fn<32, 0>(__VA_ARGS__);     \
-            else if ((ahead) >= 16) fn<16, 0>(__VA_ARGS__);     \
-            else if ((ahead) >= 8) fn<8, 0>(__VA_ARGS__);       \
-            else fn<0, 0>(__VA_ARGS__);                         \
-        }                                                       \
-    } while (0)
-#endif  // SNAPPY_ABLATION
+// K1 launchers: the LDS-table kernel and the global-table kernel, each in the bulk or the stream form of the parse, the
+// global-table one behind its slot cache for blocks with full-size hash tables.
 
-// What one K1 launch is made of (product: fixed; ablation build: from the SNAPPY_HIP_K1_* environment).
-struct K1Forms {
-    int ahead = kDefaultK1Ahead, ahead_lds = kDefaultK1AheadLds;
-    int form = kDefaultK1Form, form_lds = kDefaultK1FormLds, filter = kDefaultK1Filter;
-    uint32_t extra_lds = 0;
-};
-
-int k1_forms_from_env(K1Forms* f)
+// Knobs of earlier rounds' kernel forms, and values of the product's own knobs that no build implements any more, are
+// refused, not ignored: a sweep must never produce numbers labelled with a configuration that did not run.
+int check_knobs()
 {
-#ifdef SNAPPY_ABLATION
-    f->ahead = env_int("SNAPPY_HIP_K1_AHEAD", kDefaultK1Ahead);
-    f->ahead_lds = env_int("SNAPPY_HIP_K1_AHEAD_LDS", kDefaultK1AheadLds);
-    f->form = env_int("SNAPPY_HIP_K1_FORM", kDefaultK1Form);                 // 0 windowed, 1 masked, 2 bulk
-    f->form_lds = env_int("SNAPPY_HIP_K1_FORM_LDS", kDefaultK1FormLds);
-    f->filter = env_int("SNAPPY_HIP_K1_FILTER", kDefaultK1Filter);           // 0 none, 1 written bit, 2 tag class (bulk, look-ahead 64)
-    f->extra_lds = (uint32_t)env_int("SNAPPY_HIP_EXTRA_LDS", 0);             // occupancy ablation
-#else
     for (const char* name : {"SNAPPY_HIP_K1_AHEAD", "SNAPPY_HIP_K1_AHEAD_LDS", "SNAPPY_HIP_K1_FORM", "SNAPPY_HIP_K1_FORM_LDS",
                              "SNAPPY_HIP_K1_FILTER", "SNAPPY_HIP_EXTRA_LDS", "SNAPPY_HIP_LANES_PER_BLOCK", "SNAPPY_HIP_GROUP_WAVES",
                              "SNAPPY_HIP_PAIR_PER_CU"})
         if (getenv(name))
-            return fail(SNAPPY_HIP_ERR_ARG, std::string(name) + " selects an ablation kernel; this library was built without them "
-                                                                "(python tools/build_ablation.py builds libsnappy_hip_ablation.so)");
-    // values of the product's own knobs that only the ablation build implements are refused too, not remapped: a sweep run
-    // against this library by mistake must not produce numbers labelled with a configuration that never ran
+            return fail(SNAPPY_HIP_ERR_ARG, std::string(name) + " selected a kernel form of rounds 1-3 that was removed in round 4 "
+                                                                "(profiles/HISTORY.md names the commit that has them)");
     if (const char* v = getenv("SNAPPY_HIP_GT_CACHE"))
         if (*v && atoi(v) != 0 && atoi(v) != 512)
-            return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_GT_CACHE: this library has the slot cache with 512 slots or none (0); other sizes "
-                                            "are in libsnappy_hip_ablation.so (python tools/build_ablation.py)");
+            return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_GT_CACHE: the slot cache has 512 slots or is off (0)");
     if (const char* v = getenv("SNAPPY_HIP_K1_STREAM"))
         if (*v && (atoi(v) & ~3))
-            return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_K1_STREAM: bits 0 and 1 select the stream form per kernel; bit 2 (duo form) is in "
-                                            "libsnappy_hip_ablation.so only (python tools/build_ablation.py)");
-    (void)f;
-#endif
+            return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_K1_STREAM: bits 0 and 1 select the stream form per kernel (bit 2, round 3's duo form, was removed)");
     return 0;
 }
 
-void launch_lds_table_kernel(const K1Forms& f, uint32_t grid, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size,
-                             uint32_t slot_stride, uint32_t* counter)
+void launch_lds_table_kernel(uint32_t grid, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size, uint32_t slot_stride,
+                             uint32_t* counter)
 {
-#ifdef SNAPPY_ABLATION
-    if (env_int("SNAPPY_HIP_K1_STREAM", 0) & 4)                      // duo form (csrc/ablation/k1_duo_form.hpp): `grid` workgroups of two wavefronts
-        hipLaunchKernelGGL(snappy_hip::compress_blocks_duo_kernel, dim3(grid), dim3(128), snappy_hip::duo_lds_bytes(block_size), st, w,
-                           block_size, slot_stride, counter);
-    else if (env_int("SNAPPY_HIP_K1_STREAM", 0) & 1)
-        hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<64, 3>), dim3(grid), dim3(64),
-                           snappy_hip::lds_table_stream_lds_bytes(block_size), st, w, block_size, slot_stride, counter);
-    else
-        SNAPPY_K1_DISPATCH(launch_k1_lds, f.ahead_lds, f.form_lds, grid, f.extra_lds, st, w, block_size, slot_stride, counter);
-#else
     if (k1_stream_forms(block_size) & 1)
         hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<64, 3>), dim3(grid), dim3(64),
                            snappy_hip::lds_table_stream_lds_bytes(block_size), st, w, block_size, slot_stride, counter);
     else
         hipLaunchKernelGGL((snappy_hip::compress_blocks_lds_table_kernel<64, 2>), dim3(grid), dim3(64),
                            snappy_hip::lds_table_kernel_lds_bytes(block_size, true), st, w, block_size, slot_stride, counter);
-    (void)f;
-#endif
 }
 
-void launch_global_table_kernel(const K1Forms& f, uint32_t grid, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size,
-                                uint32_t slot_stride, uint32_t* tables, uint32_t* counter)
+void launch_global_table_kernel(uint32_t grid, hipStream_t st, const snappy_hip::K1Batch& w, uint32_t block_size, uint32_t slot_stride,
+                                uint32_t* tables, uint32_t* counter)
 {
-    // the slot cache in front of the global table (CachedGlobalTable), bulk or stream form
-    const int cache_slots = gt_cache_slots(block_size);
+    const bool cached = gt_cache_slots(block_size) != 0;
     const bool stream_form = (k1_stream_forms(block_size) & 2) != 0;
-#define SNAPPY_GT_CACHED(SLOTS)                                                                                                    \
-    if (cache_slots == SLOTS) {                                                                                                    \
-        if (stream_form)                                                                                                           \
-            hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 3, 1, SLOTS>), dim3(grid), dim3(64), 0, st, w, \
-                               block_size, slot_stride, tables, counter);                                                          \
-        else                                                                                                                       \
-            hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 2, 1, SLOTS>), dim3(grid), dim3(64), 0, st, w, \
-                               block_size, slot_stride, tables, counter);                                                          \
-        return;                                                                                                                    \
-    }
-    SNAPPY_GT_CACHED(512)
-#ifdef SNAPPY_ABLATION
-    SNAPPY_GT_CACHED(1024)
-    SNAPPY_GT_CACHED(256)
-#endif
-#undef SNAPPY_GT_CACHED
-#ifdef SNAPPY_ABLATION
-    if (f.filter == 2)
-        launch_k1_global_class_filtered(grid, st, w, block_size, slot_stride, tables, counter);
-    else if (f.filter)
-        SNAPPY_K1_DISPATCH_FILTERED(f.ahead, f.form, grid, st, w, block_size, slot_stride, tables, counter);
-    else
-        SNAPPY_K1_DISPATCH(launch_k1_global, f.ahead, f.form, grid, st, w, block_size, slot_stride, tables, counter);
-#else
-    if (stream_form)
+    if (cached && stream_form)
+        hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 3, 1, 512>), dim3(grid), dim3(64), 0, st, w, block_size,
+                           slot_stride, tables, counter);
+    else if (cached)
+        hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 2, 1, 512>), dim3(grid), dim3(64), 0, st, w, block_size,
+                           slot_stride, tables, counter);
+    else if (stream_form)
         hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 3, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
                            slot_stride, tables, counter);
     else
         hipLaunchKernelGGL((snappy_hip::compress_blocks_global_table_kernel<64, 2, 1>), dim3(grid), dim3(64), 0, st, w, block_size,
                            slot_stride, tables, counter);
-    (void)f;
-#endif
 }
 
 }  // namespace
@@ -617,13 +484,7 @@ int snappy_hip_debug_prof(unsigned long long* out, int reset)
 uint32_t snappy_hip_k1_lds_waves_per_cu(uint32_t block_size)
 {
     if (!block_size_ok(block_size)) return 0;
-    [[maybe_unused]] const launch_shape::DeviceShape shape = device_shape();
-#ifdef SNAPPY_ABLATION
-    if (const int pair = env_int("SNAPPY_HIP_PAIR_PER_CU", env_int("SNAPPY_HIP_LDS_WAVES", -1) >= 0 ? 0 : kDefaultPairPerCu)) {
-        const uint32_t pair_lds = (snappy_hip::pair_lds_bytes(block_size) + 1023u) & ~1023u;
-        return snappy_hip::kPairWaves * std::min<uint32_t>({(uint32_t)pair, shape.wave_slots_per_cu / snappy_hip::kPairWaves, shape.lds_per_cu / pair_lds});
-    }
-#endif
+    const launch_shape::DeviceShape shape = device_shape();
     const int forced = env_int("SNAPPY_HIP_LDS_WAVES", -1);
     return forced >= 0 ? ((uint32_t)forced + shape.cus - 1) / shape.cus : default_lds_waves_per_cu(block_size);
 }
@@ -640,13 +501,12 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
 {
     const uint64_t nb = w.first_block[w.count];
     // SNAPPY_HIP_COMPRESS_VARIANT: 3 = the concurrent launch below (default); 1 = the LDS-table kernel alone (also the path
-    // taken when no scratch is given); ablation builds only: 4 = lane-per-block SIMT experiment, 5 = four blocks per wavefront.
+    // taken when no scratch is given); the ablation build has 6 = the free-table experiment (csrc/ablation/k1_oracle_table.hpp).
     int variant = env_int("SNAPPY_HIP_COMPRESS_VARIANT", kVariantGlobalTable);
     if (variant == kVariantGlobalTable &&
         (!d_scratch || scratch_bytes < snappy_hip_compress_scratch_bytes() || ((uintptr_t)d_scratch & 255)))
         variant = kVariantLdsTable;   // no scratch: LDS-table kernel (still on the GPU)
-    K1Forms forms;
-    if (int rc = k1_forms_from_env(&forms)) return rc;
+    if (int rc = check_knobs()) return rc;
     hipStream_t st = (hipStream_t)stream;
     const launch_shape::DeviceShape shape = device_shape();
     const bool scratch_usable = d_scratch && scratch_bytes >= 256 && !((uintptr_t)d_scratch & 255);
@@ -670,52 +530,11 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
         HIP_TRY(hipGetLastError());
         return SNAPPY_HIP_OK;
     }
-    if (variant == kVariantGroup || variant == kVariantLanePerBlock) {
-        if (w.count != 1) return fail(SNAPPY_HIP_ERR_ARG, "the lane-per-block and group ablation kernels take one container per launch");
-        const uint8_t* d_in = w.in[0];
-        const uint64_t input_len = w.in_len[0];
-        uint8_t* d_slots = w.slots[0];
-        uint32_t* d_block_bytes = w.block_bytes[0];
-        const dim3 block(64);
-        if (variant == kVariantGroup) {
-            // 4 blocks per wavefront (16-lane groups); its tables are allocated lazily by the library
-            static thread_local uint32_t* group_tables = nullptr;
-            static thread_local uint64_t group_table_slots = 0;
-            const uint32_t waves = (uint32_t)env_int("SNAPPY_HIP_GROUP_WAVES", (int)shape.wave_slots());
-            const uint64_t want_groups = std::min<uint64_t>((uint64_t)waves * 4, (nb + 3) / 4 * 4);
-            const uint32_t g = (uint32_t)((want_groups + 3) / 4);
-            if (group_table_slots < (uint64_t)g * 4) {
-                if (group_tables) (void)hipFree(group_tables);
-                group_tables = nullptr;
-                HIP_TRY(hipMalloc((void**)&group_tables, (size_t)g * 4 * snappy_hip::kMaxTableEntries * sizeof(uint32_t)));
-                group_table_slots = (uint64_t)g * 4;
-            }
-            static thread_local uint32_t* group_counter = nullptr;
-            if (!group_counter) HIP_TRY(hipMalloc((void**)&group_counter, 256));
-            HIP_TRY(hipMemsetAsync(group_counter, 0, sizeof(uint32_t), st));
-            hipLaunchKernelGGL(snappy_hip::compress_blocks_group_kernel, dim3(g), block, 0, st, d_in, input_len, block_size,
-                               d_slots, slot_stride, d_block_bytes, (uint32_t)nb, group_tables, group_counter);
-        } else {
-            static thread_local uint16_t* lane_tables = nullptr;
-            static thread_local uint64_t lane_tables_blocks = 0;
-            if (lane_tables_blocks < nb) {
-                if (lane_tables) (void)hipFree(lane_tables);
-                lane_tables = nullptr;
-                HIP_TRY(hipMalloc((void**)&lane_tables, (size_t)nb * snappy_hip::kMaxTableEntries * sizeof(uint16_t)));
-                lane_tables_blocks = nb;
-            }
-            const uint32_t rep = (uint32_t)env_int("SNAPPY_HIP_LANES_PER_BLOCK", 1);
-            hipLaunchKernelGGL(snappy_hip::compress_blocks_lane_kernel, dim3((uint32_t)((nb * rep + 63) / 64)), block, 0, st, d_in,
-                               input_len, block_size, d_slots, slot_stride, d_block_bytes, (uint32_t)nb, lane_tables, rep);
-        }
-        HIP_TRY(hipGetLastError());
-        return SNAPPY_HIP_OK;
-    }
 #endif
     if (variant != kVariantGlobalTable && variant != kVariantLdsTable)
-        return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_COMPRESS_VARIANT: this build has variants 1 and 3 (ablation kernels: tools/build_ablation.py)");
+        return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_COMPRESS_VARIANT: 1 (LDS-table kernel alone) or 3 (the concurrent launch, default)");
     if (variant == kVariantLdsTable) {
-        launch_lds_table_kernel(forms, (uint32_t)nb, st, w, block_size, slot_stride, (uint32_t*)nullptr);
+        launch_lds_table_kernel((uint32_t)nb, st, w, block_size, slot_stride, (uint32_t*)nullptr);
         HIP_TRY(hipGetLastError());
         // the statistics word of the scratch (include/snappy_hip.h): every block of this launch had an LDS-table wavefront
         if (scratch_usable) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(static_cast<uint32_t*>(d_scratch) + 4), (int)nb, 1, st));
@@ -723,87 +542,41 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
     }
 
     // ---- the default: persistent grids, blocks handed out by an atomic counter kept in the first bytes of the scratch ----
-    // Wave budget per CU (MI355X: 256 CUs, 32 wave slots, 160 KiB of LDS each; device_shape()): a global-table wavefront holds the duplicate test
-    // (1 KiB) and the slot filter (2 KiB) in LDS and its tagged table in the scratch; the wavefronts whose table lives in
-    // LDS are sized by the block length.  SNAPPY_HIP_GT_WAVES overrides the number of global-table wavefronts
-    // (with SNAPPY_HIP_LDS_WAVES / round 1's launch: the TOTAL of both kinds).
+    // Wave budget per CU (MI355X: 256 CUs, 32 wave slots, 160 KiB of LDS each; device_shape()): a global-table wavefront holds
+    // the duplicate test, the slot filter (2 KiB) and, for blocks with full-size tables, the slot cache (2 KiB) in LDS and its
+    // table in the scratch; the wavefronts whose table lives in LDS are sized by the block length (csrc/launch_shape.hpp).
+    // SNAPPY_HIP_LDS_WAVES overrides the LDS-table wavefronts, SNAPPY_HIP_GT_WAVES the TOTAL of both kinds.
     uint32_t* counter = static_cast<uint32_t*>(d_scratch);
     uint32_t* tables = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_scratch) + 256);
     HIP_TRY(hipMemsetAsync(counter, 0, 32, st));   // [0] next block, [4] blocks compressed by wavefronts with an LDS table
     const int k1_stream = k1_stream_forms(block_size);
     const int gt_cache = gt_cache_slots(block_size);
-    const uint32_t g_wave_bytes = gt_cache ? ((k1_stream & 2) ? 4u << 10 : 3u << 10) + 4u * (uint32_t)gt_cache
-                                  : (k1_stream & 2) ? (2u << 10) + snappy_hip::stream_scratch_bytes(snappy_hip::kStreamSlotsGlobal)
-                                                    : ((forms.form ? 1u : 0u) + (forms.filter == 2 ? 4u : (forms.filter ? 2u : 0u))) << 10;
-    // fork / join around the caller's stream: `lds_launch` goes to the helper stream, the global-table kernel stays on `st`
-    auto co_run = [&](uint32_t g, const std::function<void(hipStream_t)>& lds_launch) -> int {
+    launch_shape::K1Knobs knobs;
+    knobs.cached_global_table = gt_cache != 0;
+    knobs.lds_wave_bytes = lds_table_wave_bytes(block_size);
+    knobs.gt_wave_bytes = gt_cache ? ((k1_stream & 2) ? 4u << 10 : 3u << 10) + 4u * (uint32_t)gt_cache
+                          : (k1_stream & 2) ? (2u << 10) + snappy_hip::stream_scratch_bytes(snappy_hip::kStreamSlotsGlobal)
+                                            : 3u << 10;
+    knobs.lds_waves_forced = env_int("SNAPPY_HIP_LDS_WAVES", -1);
+    knobs.waves_forced = env_int("SNAPPY_HIP_GT_WAVES", -1);
+    knobs.hybrid_min_blocks = (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096);     // small inputs: one kernel is enough
+    const launch_shape::K1Launch l = launch_shape::k1_default_launch(shape, knobs, nb);
+    if (l.lds_waves) {
+        // fork / join around the caller's stream: the LDS-table kernel goes to the helper stream, the global-table kernel stays
+        // on `st`; both draw blocks from the same counter, so the split balances itself
         CoRunResources* cr = nullptr;
         if (int rc = corun_resources(&cr)) return rc;
         HIP_TRY(hipEventRecord(cr->ev_begin, st));                     // after the counter memset and all prior work
         HIP_TRY(hipStreamWaitEvent(cr->helper, cr->ev_begin, 0));
-        lds_launch(cr->helper);
+        launch_lds_table_kernel(l.lds_waves, cr->helper, w, block_size, slot_stride, counter);
         HIP_TRY(hipEventRecord(cr->ev_end, cr->helper));
-        // a head start for the LDS-heavy workgroups: placed first, the 3 KiB allocations cannot fragment the LDS under them
+        // a head start for the LDS-heavy workgroups: placed first, the small allocations cannot fragment the LDS under them
         if (const int head_start = env_int("SNAPPY_HIP_LDS_HEAD_START", kDefaultLdsHeadStart))   // x 3.4 us
             hipLaunchKernelGGL(snappy_hip::delay_kernel, dim3(1), dim3(64), 0, st, (uint32_t)head_start);
-        launch_global_table_kernel(forms, g, st, w, block_size, slot_stride, tables, counter);
+        launch_global_table_kernel(l.gt_waves, st, w, block_size, slot_stride, tables, counter);
         HIP_TRY(hipStreamWaitEvent(st, cr->ev_end, 0));                // the caller's stream resumes when both are done
-        return 0;
-    };
-#ifdef SNAPPY_ABLATION   // round 2's two-wavefront LDS-table workgroups (csrc/ablation/k1_pair_kernel.hpp)
-    const int pair_req = env_int("SNAPPY_HIP_PAIR_PER_CU", env_int("SNAPPY_HIP_LDS_WAVES", -1) >= 0 ? 0 : kDefaultPairPerCu);
-    if (pair_req > 0) {
-        // Workgroups of TWO wavefronts sharing one u16 table in LDS (compress_blocks_pair_kernel): 2 x table_entries_for(
-        // block_size) bytes + 4 KiB of scratch + the token each.  What is left of the CU's LDS and wave slots goes to
-        // global-table wavefronts on the same work counter.
-        const uint32_t pair_lds = snappy_hip::pair_lds_bytes(block_size);
-        const uint32_t fit = std::min<uint32_t>(shape.wave_slots_per_cu / snappy_hip::kPairWaves, shape.lds_per_cu / ((pair_lds + 1023u) & ~1023u));
-        const uint32_t pair_per_cu = std::min<uint32_t>((uint32_t)pair_req, fit);
-        const uint32_t pair_wgs = (uint32_t)std::min<uint64_t>(nb, (uint64_t)pair_per_cu * shape.cus);
-        const uint32_t lds_left = shape.lds_per_cu - pair_per_cu * ((pair_lds + 1023u) & ~1023u);
-        uint32_t g_per_cu = shape.wave_slots_per_cu - snappy_hip::kPairWaves * pair_per_cu;
-        if (g_wave_bytes) g_per_cu = std::min(g_per_cu, lds_left / g_wave_bytes);
-        uint32_t g_waves = (uint32_t)env_int("SNAPPY_HIP_GT_WAVES", (int)(g_per_cu * shape.cus));
-        if (g_waves > shape.wave_slots()) g_waves = shape.wave_slots();
-        if (nb <= pair_wgs) g_waves = 0;                      // every block gets a workgroup of its own at once
-        const uint32_t g = (uint32_t)std::min<uint64_t>(nb, g_waves);
-        auto pair_launch = [&](hipStream_t on) {
-            hipLaunchKernelGGL(snappy_hip::compress_blocks_pair_kernel, dim3(pair_wgs), dim3(64 * snappy_hip::kPairWaves), pair_lds, on, w,
-                               block_size, slot_stride, counter);
-        };
-        if (g) {
-            if (int rc = co_run(g, pair_launch)) return rc;
-        } else {
-            pair_launch(st);
-        }
-        HIP_TRY(hipGetLastError());
-        return SNAPPY_HIP_OK;
-    }
-#endif
-    // One-wavefront LDS-table workgroups (the default): SNAPPY_HIP_LDS_WAVES of them run concurrently on the helper stream,
-    // default_lds_waves_per_cu(block_size) per CU; both kernels draw blocks from the same counter, so the split balances itself.
-    launch_shape::K1Knobs knobs;
-    knobs.cached_global_table = gt_cache != 0;
-#ifdef SNAPPY_ABLATION
-    const bool duo = (k1_stream & 4) != 0;
-    knobs.lds_wave_bytes = (duo ? snappy_hip::duo_lds_bytes(block_size)
-                            : (k1_stream & 1) ? snappy_hip::lds_table_stream_lds_bytes(block_size)
-                                              : snappy_hip::lds_table_kernel_lds_bytes(block_size, forms.form_lds != 0)) + forms.extra_lds;
-    knobs.lds_wave_slots = duo ? 2u : 1u;                    // a duo workgroup takes two wave slots
-#else
-    knobs.lds_wave_bytes = lds_table_wave_bytes(block_size);
-#endif
-    knobs.gt_wave_bytes = g_wave_bytes;
-    knobs.lds_waves_forced = env_int("SNAPPY_HIP_LDS_WAVES", -1);
-    knobs.waves_forced = env_int("SNAPPY_HIP_GT_WAVES", -1);
-    knobs.hybrid_min_blocks = (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096);     // small inputs: one kernel is enough
-    const launch_shape::K1Launch shape_l = launch_shape::k1_default_launch(shape, knobs, nb);
-    const uint32_t lds_waves = shape_l.lds_waves, g = shape_l.gt_waves;
-    if (lds_waves) {
-        if (int rc = co_run(g, [&](hipStream_t on) { launch_lds_table_kernel(forms, lds_waves, on, w, block_size, slot_stride, counter); }))
-            return rc;
     } else {
-        launch_global_table_kernel(forms, g, st, w, block_size, slot_stride, tables, counter);
+        launch_global_table_kernel(l.gt_waves, st, w, block_size, slot_stride, tables, counter);
     }
     HIP_TRY(hipGetLastError());
     return SNAPPY_HIP_OK;
@@ -925,51 +698,16 @@ static int launch_decompress(const snappy_hip::K2Batch& w, uint32_t block_size, 
     if (int rc = next_work_counter(&wc, st)) return rc;
     uint32_t* counter = wc.ptr;
     const launch_shape::DeviceShape shape = device_shape();
-    const uint32_t resident = shape.wave_slots();
-    const uint32_t k2_cap = (uint32_t)std::max(1, env_int("SNAPPY_HIP_K2_WAVES", (int)resident));   // fewer wavefronts leave slots for a co-running kernel
-#ifdef SNAPPY_ABLATION
-    // SNAPPY_HIP_DECOMPRESS_VARIANT: 0 = output window in LDS only, 1 (default) = output window in global memory only,
-    // 2 = both forms concurrently (no gain measured for K2): SNAPPY_HIP_K2_LDS_WAVES LDS-window wavefronts on a helper stream
-    // beside the global-window ones, all drawing blocks from one counter.
-    const int variant = env_int("SNAPPY_HIP_DECOMPRESS_VARIANT", kDefaultDecompressVariant);
-    const uint32_t lds_bytes = (block_size + 15u) & ~15u;
-    uint32_t lds_waves = 0;
-    if (variant == 0) lds_waves = (uint32_t)std::min<uint64_t>(nb, resident);
-    else if (variant == 2 && nb >= (uint64_t)env_int("SNAPPY_HIP_HYBRID_MIN_BLOCKS", 4096))
-        lds_waves = (uint32_t)env_int("SNAPPY_HIP_K2_LDS_WAVES", lds_bytes > 32768 ? 512 : 1024);
-    const uint32_t glob_waves = (variant == 0) ? 0 : (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nb, k2_cap), resident - std::min(lds_waves, resident / 2));
-    if (lds_waves && glob_waves) {
-        CoRunResources* cr = nullptr;
-        if (int rc = corun_resources(&cr)) return rc;
-        hipStream_t helper = cr->helper;
-        hipEvent_t ev_begin = cr->ev_begin, ev_end = cr->ev_end;
-        HIP_TRY(hipEventRecord(ev_begin, st));
-        HIP_TRY(hipStreamWaitEvent(helper, ev_begin, 0));
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_element_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, helper, w, block_size, counter);
-        HIP_TRY(hipEventRecord(ev_end, helper));
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel, dim3(glob_waves), dim3(64), 0, st, w, block_size, counter);
-        HIP_TRY(hipStreamWaitEvent(st, ev_end, 0));
-    } else if (lds_waves) {
-        hipLaunchKernelGGL(snappy_hip::decompress_blocks_element_kernel<true>, dim3(lds_waves), dim3(64), lds_bytes, st, w, block_size, counter);
-    } else
-#else
-    if ((getenv("SNAPPY_HIP_DECOMPRESS_VARIANT") && env_int("SNAPPY_HIP_DECOMPRESS_VARIANT", kDefaultDecompressVariant) != kDefaultDecompressVariant) ||
-        (getenv("SNAPPY_HIP_K2_BATCH") && !env_int("SNAPPY_HIP_K2_BATCH", 1))) {
+    const uint32_t k2_cap = (uint32_t)std::max(1, env_int("SNAPPY_HIP_K2_WAVES", (int)shape.wave_slots()));   // fewer wavefronts leave slots for a co-running kernel
+    if (getenv("SNAPPY_HIP_DECOMPRESS_VARIANT") || getenv("SNAPPY_HIP_K2_BATCH") || getenv("SNAPPY_HIP_K2_LDS_WAVES")) {
         (void)work_counter_launched(wc, st);
-        return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_DECOMPRESS_VARIANT / SNAPPY_HIP_K2_BATCH select an ablation kernel; this library was built without them");
+        return fail(SNAPPY_HIP_ERR_ARG, "SNAPPY_HIP_DECOMPRESS_VARIANT / SNAPPY_HIP_K2_BATCH / SNAPPY_HIP_K2_LDS_WAVES selected decoder forms of "
+                                        "rounds 1-2 that were removed in round 4 (profiles/HISTORY.md)");
     }
-#endif
-    {
-        const uint32_t glob = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nb, k2_cap), resident);
-#ifdef SNAPPY_ABLATION
-        if (!env_int("SNAPPY_HIP_K2_BATCH", 1))       // round 1's element-at-a-time loop
-            hipLaunchKernelGGL(snappy_hip::decompress_blocks_element_kernel<false>, dim3(glob), dim3(64), 0, st, w, block_size, counter);
-        else
-#endif
-            hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel, dim3(glob), dim3(64), 0, st, w, block_size, counter);
-    }
+    hipLaunchKernelGGL(snappy_hip::decompress_blocks_kernel, dim3(launch_shape::k2_launch_waves(shape, nb, (int)k2_cap)), dim3(64), 0, st, w,
+                       block_size, counter);
     const hipError_t launched = hipGetLastError();
-    if (int rc = work_counter_launched(wc, st)) return rc;       // after the join: the event covers both kernels
+    if (int rc = work_counter_launched(wc, st)) return rc;
     HIP_TRY(launched);
     return SNAPPY_HIP_OK;
 }

@@ -304,12 +304,6 @@ __device__ __forceinline__ void lds_st32u(lds_bytes_t p, uint32_t v)
 }
 #endif
 
-#ifdef SNAPPY_ABLATION
-}  // namespace snappy_hip
-#include "ablation/k1_tables.hpp"
-namespace snappy_hip {
-#endif
-
 // Emulator only: aborts when two lanes of one (emulated) store instruction write the same table entry -- on the GPU it is
 // not defined which of them lands last.  All lanes call, between two collectives.
 #ifdef SNAPPY_EMU
@@ -524,12 +518,6 @@ __device__ __forceinline__ uint32_t emit_literal_windowed(uint8_t* __restrict__ 
     return op + hdr + len;
 }
 
-#ifdef SNAPPY_ABLATION
-}  // namespace snappy_hip
-#include "ablation/k1_windowed_form.hpp"
-namespace snappy_hip {
-#endif
-
 // floor(x / d) for x < 64, 1 <= d < 64:  (x * kRecip16[d]) >> 16  with kRecip16[d] = 65536/d + 1
 __constant__ uint32_t kRecip16[64] = {
         0, 65537, 32769, 21846, 16385, 13108, 10923,  9363,  8193,  7282,  6554,  5958,  5462,  5042,  4682,  4370,
@@ -709,12 +697,6 @@ struct MaskedWindowState {
         }
     }
 };
-
-#ifdef SNAPPY_ABLATION
-}  // namespace snappy_hip
-#include "ablation/k1_masked_form.hpp"
-namespace snappy_hip {
-#endif
 
 // ---------------------------------------------------------------------------
 // K1, bulk form: the masked form with the per-match work moved off the scalar chain.  Within one window, for as long as
@@ -1216,16 +1198,7 @@ __global__ __launch_bounds__(64) void compress_blocks_lds_table_kernel(const K1B
         const uint64_t start = (uint64_t)lb * block_size;
         const uint64_t left = in_len - start;
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
-#ifdef SNAPPY_ABLATION
-        if constexpr (kForm == 1)
-            compress_one_block_masked<LdsTable, kAhead>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out,
-                                                        (lds_bytes_t)dup_scratch);
-        else if constexpr (kForm == 0)
-            compress_one_block_windowed<LdsTable, kAhead>(in, start, in_len, n, slot, LdsTable{table}, lane, bytes_out);
-        else
-#else
-        static_assert(kForm == 2 || kForm == 3, "the product ships the bulk and stream forms; other forms need -DSNAPPY_ABLATION");
-#endif
+        static_assert(kForm == 2 || kForm == 3, "the bulk (2) and the stream (3) form of the parse exist; rounds 1-2's other forms are in the history (profiles/HISTORY.md)");
         if constexpr (kForm == 3)   // (launched with lds_table_stream_lds_bytes(block_size) of dynamic LDS)
         {
             SoloMate solo;
@@ -1247,16 +1220,11 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
 {
     const uint32_t num_blocks = w.first_block[w.count];
     __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kForm == 3 ? stream_scratch_bytes(kStreamSlotsGlobal) : (kForm ? kDupSlots : 16)];
-    __shared__ __attribute__((aligned(16))) uint32_t slot_state[kFilter == 2 ? kMaxTableEntries / 16 : (kFilter ? kMaxTableEntries / 32 : 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t slot_state[kMaxTableEntries / 32];   // the "slot written in this block" filter
     __shared__ __attribute__((aligned(16))) uint32_t slot_cache[kCacheSlots ? kCacheSlots : 4];
     const uint32_t lane = threadIdx.x;
-#ifdef SNAPPY_ABLATION
-    using Narrow = typename std::conditional<kFilter == 2, ClassFilteredGlobalTable,
-                                             typename std::conditional<kFilter == 1, FilteredGlobalTable, TaggedGlobalTable>::type>::type;
-#else
-    static_assert((kForm == 2 || kForm == 3) && kFilter == 1, "the product ships the bulk and stream forms behind the slot filter; other forms need -DSNAPPY_ABLATION");
+    static_assert((kForm == 2 || kForm == 3) && kFilter == 1, "the bulk (2) and the stream (3) form behind the slot filter exist; rounds 1-2's other forms are in the history (profiles/HISTORY.md)");
     using Narrow = FilteredGlobalTable;
-#endif
     using Table = typename std::conditional<kCacheSlots != 0, CachedGlobalTable<(kCacheSlots ? kCacheSlots : 1024u)>, Narrow>::type;
     Table table;
     if constexpr (kCacheSlots != 0) {
@@ -1270,12 +1238,6 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
         table.written = (lds_words_t)slot_state;
         table.empty = 0;
     }
-#ifdef SNAPPY_ABLATION
-    if constexpr (kFilter == 2) {
-        table.cls = (lds_words_t)slot_state;
-        table.empty = 0;
-    }
-#endif
     for (;;) {
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(next_block, 1u);
@@ -1290,13 +1252,6 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
         const uint64_t start = (uint64_t)lb * block_size;
         const uint64_t left = in_len - start;
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
-#ifdef SNAPPY_ABLATION
-        if constexpr (kForm == 1)
-            compress_one_block_masked<Table, kAhead>(in, start, in_len, n, slot, table, lane, bytes_out, (lds_bytes_t)dup_scratch);
-        else if constexpr (kForm == 0)
-            compress_one_block_windowed<Table, kAhead>(in, start, in_len, n, slot, table, lane, bytes_out);
-        else
-#endif
         if constexpr (kForm == 3)
         {
             SoloMate solo;
@@ -1307,24 +1262,6 @@ __global__ __launch_bounds__(64) void compress_blocks_global_table_kernel(const 
             compress_one_block_bulk<Table, kAhead>(in, start, in_len, n, slot, table, lane, bytes_out, (lds_bytes_t)dup_scratch);
     }
 }
-
-#ifdef SNAPPY_ABLATION
-}  // namespace snappy_hip
-#include "ablation/k1_pair_kernel.hpp"
-namespace snappy_hip {
-#endif
-
-#ifdef SNAPPY_ABLATION
-}  // namespace snappy_hip
-#include "ablation/k1_simt_kernels.hpp"
-namespace snappy_hip {
-#endif
-
-#ifdef SNAPPY_ABLATION
-}  // namespace snappy_hip
-#include "ablation/k1_duo_form.hpp"
-namespace snappy_hip {
-#endif
 
 #ifdef SNAPPY_ABLATION
 }  // namespace snappy_hip
@@ -2069,6 +2006,3 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(80))) void decom
 
 }  // namespace snappy_hip
 
-#ifdef SNAPPY_ABLATION
-#include "ablation/k2_element_loop.hpp"
-#endif

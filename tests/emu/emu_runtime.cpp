@@ -214,31 +214,22 @@ void launch(uint32_t grid, uint32_t block, const std::function<void()>& body)
 // ---------------------------------------------------------------------------
 extern "C" {
 
-// Runs compress_blocks_kernel + scan + gather on the CPU emulator.  Returns stream length.
-// variant = kernel form (1 LDS table, 3 global table, 4 lane-per-block, 5 group) + 100 * look-ahead code
-// (0 = EMU_K1_AHEAD, 1 = off, 2 = 4, 3 = 8, 4 = 16, 5 = 64) + 1000 for the masked form, + 2000 for the bulk form (chunk = look-ahead, needs > 0), + 3000 for the stream form,
-// + 10000 for the LDS slot filter in front of the global table, + 20000 for the tag-class filter (bulk form only),
-// + 40000 / + 50000 for the write-back slot cache of 512 / 256 slots (bulk and stream form, look-ahead 64)
-#define EMU_AHEAD_DISPATCH(code, CALL)                         \
-    switch (code) {                                            \
-    case 1: { constexpr uint32_t kA = 0; CALL; } break;        \
-    case 2: { constexpr uint32_t kA = 4; CALL; } break;        \
-    case 3: { constexpr uint32_t kA = 8; CALL; } break;        \
-    case 4: { constexpr uint32_t kA = 16; CALL; } break;       \
-    case 5: { constexpr uint32_t kA = 64; CALL; } break;       \
-    default: { constexpr uint32_t kA = EMU_K1_AHEAD; CALL; }   \
-    }
-
+// Runs K1 + scan + gather on the CPU emulator.  Returns the stream length (0: unknown variant).
+// variant = table kind * 10000 + form * 1000 + 500 + kernel:
+//   kernel 1 = LDS-table kernel (one workgroup per block), 3 = global-table kernel (persistent, a few workgroups on one counter)
+//   form   2 = bulk form, 3 = stream form of the parse
+//   table  (global-table kernel) 1 = behind the LDS slot filter, 4 / 5 = behind the write-back slot cache of 512 / 256 slots
+// e.g. 43503 = the product's default for blocks of more than 8 KiB, 12503 = for smaller ones, 3501 = the LDS-table kernel.
+// (Rounds 1-3's other forms -- windowed / masked parses, look-ahead widths, lane-per-block, group, pair and duo kernels -- were
+// removed in round 4 together with csrc/ablation/; profiles/HISTORY.md.)
 uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_t* stream, uint64_t stream_cap, int variant)
 {
-    const int filter_kind = variant / 10000;     // 1 = written bit, 2 = tag class
-    const bool filtered = filter_kind != 0;
-    variant %= 10000;
-    const int form = variant / 1000;
-    const bool masked = form != 0;
-    variant %= 1000;
-    const int ahead_code = variant / 100;
-    variant %= 100;
+    const int table_kind = variant / 10000;
+    const int form = (variant % 10000) / 1000;
+    const int kernel = variant % 100;
+    if ((form != 2 && form != 3) || (kernel != 1 && kernel != 3) || (kernel == 3 && table_kind != 1 && table_kind != 4 && table_kind != 5) ||
+        (kernel == 1 && table_kind != 0))
+        return 0;
     const uint64_t need = 4ull + 32ull + block_size + block_size / 6;
     const uint32_t stride = (uint32_t)((need + 15) & ~15ull);
     const uint32_t nb = (uint32_t)((n + block_size - 1) / block_size);
@@ -250,7 +241,6 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
     // padded copy so the same (unaligned, slightly over-reading) loads stay inside the allocation
     std::vector<uint8_t> inbuf(n + 64, 0x55);
     if (n) memcpy(inbuf.data(), in, n);
-    std::vector<uint16_t> lane_tables(variant == 4 ? (size_t)nb * 16384 : 1);
     snappy_hip::K1Batch w{};
     w.count = 1;
     w.first_block[0] = 0;
@@ -259,86 +249,24 @@ uint64_t emu_compress_variant(const uint8_t* in, uint64_t n, uint32_t block_size
     w.in_len[0] = n;
     w.slots[0] = slots.data();
     w.block_bytes[0] = bytes.data();
-    if (nb && variant == 3) {
-        // persistent kernel: a few workgroups pull blocks from the shared counter
+    if (nb && kernel == 3) {
         const uint32_t grid = nb < 3 ? nb : 3;
-        std::vector<uint32_t> tables((size_t)grid * 16384, 0xBEEFBEEFu);
+        std::vector<uint32_t> tables((size_t)grid * 16384, 0xBEEFBEEFu);     // never initialised on the GPU either
         uint32_t counter = 0;
         emu::launch(grid, 64, [&] {
-            if (filter_kind == 4) {              // write-back cache of slots in LDS in front of u16 global entries
-                if (form == 3)
-                    snappy_hip::compress_blocks_global_table_kernel<64, 3, 1, 512>(w, block_size, stride, tables.data(), &counter);
-                else
-                    snappy_hip::compress_blocks_global_table_kernel<64, 2, 1, 512>(w, block_size, stride, tables.data(), &counter);
-            } else if (filter_kind == 5) {
-                if (form == 3)
-                    snappy_hip::compress_blocks_global_table_kernel<64, 3, 1, 256>(w, block_size, stride, tables.data(), &counter);
-                else
-                    snappy_hip::compress_blocks_global_table_kernel<64, 2, 1, 256>(w, block_size, stride, tables.data(), &counter);
-            } else if (filter_kind == 2) {
-                EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 2, 2>(
-                                                   w, block_size, stride, tables.data(), &counter)));
-            } else if (filtered) {
-                if (form == 3) {
-                    snappy_hip::compress_blocks_global_table_kernel<64, 3, 1>(w, block_size, stride, tables.data(), &counter);
-                } else if (form == 2) {
-                    EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 2, 1>(
-                                                       w, block_size, stride, tables.data(), &counter)));
-                } else if (form == 1) {
-                    EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 1, 1>(
-                                                       w, block_size, stride, tables.data(), &counter)));
-                } else {
-                    EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<kA, 0, 1>(
-                                                       w, block_size, stride, tables.data(), &counter)));
-                }
-            } else if (form == 2) {
-                EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 2>(
-                                                   w, block_size, stride, tables.data(), &counter)));
-            } else if (masked) {
-                EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_global_table_kernel<(kA ? kA : 8), 1>(
-                                                   w, block_size, stride, tables.data(), &counter)));
-            } else {
-                EMU_AHEAD_DISPATCH(ahead_code, snappy_hip::compress_blocks_global_table_kernel<kA>(
-                                                   w, block_size, stride, tables.data(), &counter));
-            }
+            if (table_kind == 4 && form == 3) snappy_hip::compress_blocks_global_table_kernel<64, 3, 1, 512>(w, block_size, stride, tables.data(), &counter);
+            else if (table_kind == 4) snappy_hip::compress_blocks_global_table_kernel<64, 2, 1, 512>(w, block_size, stride, tables.data(), &counter);
+            else if (table_kind == 5 && form == 3) snappy_hip::compress_blocks_global_table_kernel<64, 3, 1, 256>(w, block_size, stride, tables.data(), &counter);
+            else if (table_kind == 5) snappy_hip::compress_blocks_global_table_kernel<64, 2, 1, 256>(w, block_size, stride, tables.data(), &counter);
+            else if (form == 3) snappy_hip::compress_blocks_global_table_kernel<64, 3, 1>(w, block_size, stride, tables.data(), &counter);
+            else snappy_hip::compress_blocks_global_table_kernel<64, 2, 1>(w, block_size, stride, tables.data(), &counter);
         });
-    } else if (nb && variant == 6) {
-        // two-wavefront workgroups, one shared LDS table per block; a few workgroups pull blocks from the counter
-        const uint32_t grid = nb < 3 ? nb : 3;
-        uint32_t counter[8] = {0};
-        emu::launch(grid, 128, [&] { snappy_hip::compress_blocks_pair_kernel(w, block_size, stride, counter); });
-    } else if (nb && variant == 7) {
-        // duo form: two-wavefront workgroups (parser + mate), a few workgroups pull blocks from the counter
-        const uint32_t grid = nb < 3 ? nb : 3;
-        uint32_t counter[8] = {0};
-        emu::launch(grid, 128, [&] { snappy_hip::compress_blocks_duo_kernel(w, block_size, stride, counter); });
-    } else if (nb && variant == 5) {
-        const uint32_t grid = nb < 8 ? 1 : 2;
-        std::vector<uint32_t> tables((size_t)grid * 4 * 16384, 0xBEEFBEEFu);
-        uint32_t group_counter = 0;
-        emu::launch(grid, 64, [&] {
-            snappy_hip::compress_blocks_group_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb,
-                                                     tables.data(), &group_counter);
-        });
-    } else if (nb)
+    } else if (nb) {
         emu::launch(nb, 64, [&] {
-            if (variant == 4) {
-                if (emu::bidx().x * 64 < nb)
-                    snappy_hip::compress_blocks_lane_kernel(inbuf.data(), n, block_size, slots.data(), stride, bytes.data(), nb, lane_tables.data(), 1);
-            } else
-                if (form == 3) {
-                    snappy_hip::compress_blocks_lds_table_kernel<64, 3>(w, block_size, stride, nullptr);
-                } else if (form == 2) {
-                    EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_lds_table_kernel<(kA ? kA : 8), 2>(
-                                                       w, block_size, stride, nullptr)));
-                } else if (masked) {
-                    EMU_AHEAD_DISPATCH(ahead_code, (snappy_hip::compress_blocks_lds_table_kernel<(kA ? kA : 8), 1>(
-                                                       w, block_size, stride, nullptr)));
-                } else {
-                    EMU_AHEAD_DISPATCH(ahead_code, snappy_hip::compress_blocks_lds_table_kernel<kA>(
-                                                       w, block_size, stride, nullptr));
-                }
+            if (form == 3) snappy_hip::compress_blocks_lds_table_kernel<64, 3>(w, block_size, stride, nullptr);
+            else snappy_hip::compress_blocks_lds_table_kernel<64, 2>(w, block_size, stride, nullptr);
         });
+    }
     emu::launch(1, 1024, [&] {
         snappy_hip::scan_block_bytes_kernel(bytes.data(), nb, (uint32_t)n, block_size, stream, offsets.data(), &stream_len);
     });
@@ -409,14 +337,8 @@ int emu_decompress_variant(const uint8_t* stream, uint64_t stream_len, uint32_t 
     kb.total_len[0] = total_len;
     kb.out[0] = out;
     kb.status[0] = status.data();
-    emu::launch(nb < 3 ? nb : 3, 64, [&] {
-        if (variant == 0)
-            snappy_hip::decompress_blocks_element_kernel<true>(kb, block_size, &k2_counter);
-        else if (variant == 3)
-            snappy_hip::decompress_blocks_kernel(kb, block_size, &k2_counter);      // per-window batch
-        else
-            snappy_hip::decompress_blocks_element_kernel<false>(kb, block_size, &k2_counter);
-    });
+    (void)variant;                                                       // (one decoder: the per-window batch)
+    emu::launch(nb < 3 ? nb : 3, 64, [&] { snappy_hip::decompress_blocks_kernel(kb, block_size, &k2_counter); });
     for (uint32_t i = 0; i < nb; ++i)
         if (status[i] != 0) return 1;
     return 0;

@@ -388,8 +388,8 @@ def test_decoder_agrees_with_oracle_on_damaged_element_streams(shb):
 # ---- every kernel variant produces the same bytes ------------------------------------------------------
 
 # The shipped K1 / K2 set: the concurrent launch (global-table + LDS-table kernels), each kernel alone, tiny grids, the bulk
-# and the stream form of the parse.  The non-default forms of rounds 1 and 2 (incl. the two-wavefront LDS form) live in
-# csrc/ablation/ and are checked by tests/test_gpu_ablation.py against their own build.
+# and the stream form of the parse, with and without the slot cache.  (The other kernel forms of rounds 1-3 were removed in
+# round 4; profiles/HISTORY.md.)
 TINY_HYBRID = {"SNAPPY_HIP_LDS_WAVES": "5", "SNAPPY_HIP_GT_WAVES": "11", "SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"}
 
 

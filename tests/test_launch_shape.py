@@ -34,9 +34,13 @@ int main() {
         CHECK(l.lds_waves + l.gt_waves <= d.wave_slots());
         const K1Launch few = k1_default_launch(d, k, 1000);            // below SNAPPY_HIP_HYBRID_MIN_BLOCKS: one kernel
         CHECK(few.lds_waves == 0 && few.gt_waves == std::min(1000u, 26 * d.cus));   // 160 KiB / 6 KiB = 26 per CU requested
-        // the small-input rule: one LDS-table wavefront per SIMD at most
+        // the small-input rule: as many blocks as LDS-table wavefronts fit at once (36 KiB each: four per CU), at most two per
+        // SIMD (-b 8192, 20 KiB each: eight per CU; -b 4096, 12 KiB: LDS would hold 13, the rule stops at eight)
         CHECK(small_input_takes_lds_kernel_alone(d, k.lds_wave_bytes, 4 * d.cus));
         CHECK(!small_input_takes_lds_kernel_alone(d, k.lds_wave_bytes, 4 * d.cus + 1));
+        CHECK(small_input_takes_lds_kernel_alone(d, 2 * lds_table_entries(8192) + 4096, 8 * d.cus));
+        CHECK(!small_input_takes_lds_kernel_alone(d, 2 * lds_table_entries(8192) + 4096, 8 * d.cus + 1));
+        CHECK(!small_input_takes_lds_kernel_alone(d, 2 * lds_table_entries(4096) + 4096, 8 * d.cus + 1));
         CHECK(k2_launch_waves(d, 262144, 0) == d.wave_slots() && k2_launch_waves(d, 10, 0) == 10 && k2_launch_waves(d, 262144, 512) == 512);
     }
     // without the slot cache (round 2's mix): three LDS-table wavefronts per CU beside 3 KiB global-table ones
