@@ -155,10 +155,13 @@ SNAPPY_HIP_API uint32_t snappy_hip_parse_header(const uint8_t *src, uint64_t ava
  * d_in must be 16-byte aligned.  `stream` is a hipStream_t (NULL = default stream).
  *
  * d_scratch: 256-byte aligned device workspace of snappy_hip_compress_scratch_bytes() bytes (one 64 KiB
- * tagged hash table per resident wavefront + a work counter; contents need not be initialised, the buffer must
- * not be shared by launches that run concurrently).  If NULL or too small the LDS-table kernel is used
- * instead (lower occupancy, same bytes).  After the launch, the u32 at byte 16 of the scratch holds the number
- * of blocks that were compressed by the LDS-table wavefronts of the concurrent launch (statistics only).
+ * hash table per wavefront slot of the CURRENT device + a work counter: 512 MiB on a whole MI355X, 64 MiB on a
+ * 32-CU partition -- the size is taken from hipGetDeviceProperties, so ask with the device selected that will
+ * run the launch; contents need not be initialised, the buffer must not be shared by launches that run
+ * concurrently).  If NULL or too small the LDS-table kernel is used instead (lower occupancy, same bytes).
+ * After EVERY launch that was given a scratch, the u32 at byte 16 of the scratch holds the number of blocks that
+ * were compressed by LDS-table wavefronts (statistics only): all of them when a small input went to the
+ * LDS-table kernel alone, none with SNAPPY_HIP_LDS_WAVES=0.
  */
 SNAPPY_HIP_API uint64_t snappy_hip_compress_scratch_bytes(void);
 /* Wavefronts per CU whose hash table lives in LDS in a default K1 launch at this block size (the table is sized by the
