@@ -57,12 +57,71 @@ struct RecMate {
     }
 };
 
+// The same experiment WITH the costs a table-free pass 2 would have (kernel below, kWithCosts): the answers still come from
+// the records, but every gather also does what reconstructing them would take -- read the position's parse-independent
+// predecessor (`prevw`: nearest earlier position with the same hash before the window, a second host-made array, one
+// coalesced u16 per lane), test its "inserted" bit in a 4 KiB LDS bitmap that the commits really maintain, and for the lanes
+// whose predecessor was not inserted fetch the memoised candidate E[prevw] from a per-wavefront global array (a dependent
+// random 2-byte read, awaited before the candidate bytes are asked for, as a real pass 2 would have to) -- and every window
+// stores its 64 memoised candidates (one coalesced store) and pays two cross-lane permutes for resolving them.
+struct OracleCostTable {
+    static constexpr bool kCollectiveStore = true;
+    static constexpr bool kGathersOnce = true;
+    const uint32_t* __restrict__ rec;
+    const uint16_t* __restrict__ prevw;
+    uint16_t* __restrict__ memo;            // E[]: 64 KiB per wavefront in the scratch
+    lds_words_t inserted;                   // one bit per position of the block
+    __device__ __forceinline__ void init(uint32_t, uint32_t, uint32_t lane) const
+    {
+        for (uint32_t i = lane; i < 1024u; i += kWave) inserted[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ static bool certain_miss(uint32_t, uint32_t) { return false; }
+    __device__ __forceinline__ OracleCostTable with_empty(uint32_t) const { return *this; }
+    __device__ __forceinline__ uint32_t load_lane(uint32_t, uint32_t mine) const
+    {
+        const uint32_t pos = mine & 0xffffu;
+        const uint32_t c1 = prevw[pos];
+        const bool ins = (inserted[c1 >> 5] >> (c1 & 31u)) & 1u;
+        uint32_t e = 0;
+        if (c1 != 0u && !ins) e = memo[c1];
+#ifndef SNAPPY_EMU
+        asm volatile("" ::"v"(e));          // the memoised candidate is needed HERE (the candidate bytes are fetched from it)
+#endif
+        return (mine & 0xffff0000u) | (rec[pos] & 0xffffu);
+    }
+    __device__ __forceinline__ void store_masked(unsigned long long m, uint32_t, uint32_t pos, uint32_t lane) const
+    {
+        const uint32_t base = (pos - lane) & 0xffffu;            // stream_store: the window's base; stream_put: garbage-free enough (lane 0 only)
+        if (lane < 2u) lds_or(inserted + (((base >> 5) + lane) & 1023u), (uint32_t)(m >> (32u * lane)));
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void put(uint32_t, uint32_t, uint32_t) const {}
+};
+
+struct RecCostMate : RecMate {
+    uint16_t* __restrict__ memo;
+    template <uint32_t kSlots>
+    __device__ __forceinline__ void analysis(StreamDup& d, const StreamWindow& w, lds_bytes_t scratch, uint32_t lane)
+    {
+        RecMate::analysis<kSlots>(d, w, scratch, lane);
+        // once per window: resolve the memoised candidates along the in-window chains (two rounds of pointer jumping) and store them
+        uint32_t v = d.j1 + w.base;
+        v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d.j1 & 63u) << 2), (int)v) + (v & 1u);
+        v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((v & 63u) << 2), (int)v) + (v & 3u);
+        memo[w.base + lane] = (uint16_t)v;
+    }
+};
+
 // one container per launch; rec = records of the whole container (input_len + 64 entries)
+template <bool kWithCosts>
 __global__ __launch_bounds__(64) void compress_blocks_oracle_kernel(const K1Batch w, uint32_t block_size, uint32_t slot_stride,
-                                                                    const uint32_t* __restrict__ rec, uint32_t* next_block)
+                                                                    const uint32_t* __restrict__ rec, const uint16_t* __restrict__ prevw,
+                                                                    uint16_t* __restrict__ memo_scratch, uint32_t* next_block)
 {
     const uint32_t num_blocks = w.first_block[w.count];
     __shared__ __attribute__((aligned(16))) uint8_t dup_scratch[kDupSlots];     // the bulk form's race tables (block tails, stride > 1)
+    __shared__ __attribute__((aligned(16))) uint32_t inserted_bits[kWithCosts ? 1024 : 4];   // 32768 positions
     const uint32_t lane = threadIdx.x;
     for (;;) {
         uint32_t b = 0;
@@ -76,10 +135,22 @@ __global__ __launch_bounds__(64) void compress_blocks_oracle_kernel(const K1Batc
         const uint64_t start = (uint64_t)b * block_size;
         const uint64_t left = in_len - start;
         const uint32_t n = (left < block_size) ? (uint32_t)left : block_size;
-        OracleTable table{rec + start};
-        RecMate mate{rec + start};
-        compress_one_block_stream<OracleTable, kStreamSlotsGlobal>(in, start, in_len, n, slot, table, lane, bytes_out, (lds_bytes_t)dup_scratch,
-                                                                   mate);
+        if constexpr (kWithCosts) {
+            // 64 KiB of the scratch per wavefront (the launcher caps the grid at the device's wavefront slots, which is what the
+            // scratch is sized for): 32768 u16 entries, one per position of a block of up to 32768 bytes -- the experiment's block size
+            uint16_t* memo = memo_scratch + (size_t)blockIdx.x * 32768u;
+            OracleCostTable table{rec + start, prevw + start, memo, (lds_words_t)inserted_bits};
+            RecCostMate mate;
+            mate.rec = rec + start;
+            mate.memo = memo;
+            compress_one_block_stream<OracleCostTable, kStreamSlotsGlobal>(in, start, in_len, n, slot, table, lane, bytes_out,
+                                                                           (lds_bytes_t)dup_scratch, mate);
+        } else {
+            OracleTable table{rec + start};
+            RecMate mate{rec + start};
+            compress_one_block_stream<OracleTable, kStreamSlotsGlobal>(in, start, in_len, n, slot, table, lane, bytes_out,
+                                                                       (lds_bytes_t)dup_scratch, mate);
+        }
     }
 }
 

@@ -106,8 +106,9 @@ constexpr int kVariantLdsTable = 1, kVariantGlobalTable = 3;
 // host-made records (csrc/ablation/k1_oracle_table.hpp, gate (b) of round 4's two-pass question).  The kernel forms of rounds
 // 1-3 that do not ship (windowed / masked parses, unfiltered and class-filtered tables, lane-per-block, four blocks per
 // wavefront, two-wavefront LDS forms, K2's element loop) were removed in round 4; they are in the history (profiles/HISTORY.md).
-constexpr int kVariantOracle = 6;
+constexpr int kVariantOracle = 6, kVariantOracleWithCosts = 7;
 const uint32_t* g_oracle_records = nullptr;    // device array, one u32 per input position (tools/gate_b_ceiling.py)
+const uint16_t* g_oracle_prevw = nullptr;      // device array, one u16 per input position (variant 7)
 #endif
 constexpr int kDefaultLdsHeadStart = 6; // ~20 us for the LDS-table workgroups to be placed before the global-table kernel starts
 constexpr int kDefaultGtCache = 512;    // SNAPPY_HIP_GT_CACHE: slots of the write-back cache in LDS in front of the global table, for blocks with full-size hash tables; 0 = none
@@ -467,6 +468,7 @@ uint32_t snappy_hip_parse_header(const uint8_t* src, uint64_t avail, uint32_t* t
 #ifdef SNAPPY_ABLATION
 // ablation build only: the records OracleTable / RecMate read (csrc/ablation/k1_oracle_table.hpp)
 void snappy_hip_debug_set_oracle_records(const uint32_t* d_records) { g_oracle_records = d_records; }
+void snappy_hip_debug_set_oracle_prevw(const uint16_t* d_prevw) { g_oracle_prevw = d_prevw; }
 #endif
 
 #ifdef SNAPPY_PROF
@@ -519,14 +521,21 @@ static int launch_compress(const snappy_hip::K1Batch& w, uint32_t block_size, ui
         launch_shape::small_input_takes_lds_kernel_alone(shape, snappy_hip::lds_table_stream_lds_bytes(block_size), nb))
         variant = kVariantLdsTable;
 #ifdef SNAPPY_ABLATION
-    if (variant == kVariantOracle) {     // ceiling experiment (csrc/ablation/k1_oracle_table.hpp): the table answered from host-made records
-        if (w.count != 1 || !g_oracle_records || !d_scratch)
-            return fail(SNAPPY_HIP_ERR_ARG, "variant 6 takes one container, a scratch and snappy_hip_debug_set_oracle_records()");
+    if (variant == kVariantOracle || variant == kVariantOracleWithCosts) {     // ceiling experiment (csrc/ablation/k1_oracle_table.hpp)
+        const bool costs = variant == kVariantOracleWithCosts;
+        if (w.count != 1 || !g_oracle_records || !d_scratch ||
+            (costs && (!g_oracle_prevw || scratch_bytes < snappy_hip_compress_scratch_bytes() || block_size > 32768u)))
+            return fail(SNAPPY_HIP_ERR_ARG, "variants 6 / 7 take one container, a scratch and snappy_hip_debug_set_oracle_records() (7: + _prevw())");
         uint32_t* counter = static_cast<uint32_t*>(d_scratch);
+        uint16_t* memo = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(d_scratch) + 256);
         HIP_TRY(hipMemsetAsync(counter, 0, 32, st));
-        const uint32_t waves = (uint32_t)std::min<uint64_t>(nb, (uint64_t)env_int("SNAPPY_HIP_GT_WAVES", (int)(20 * shape.cus)));
-        hipLaunchKernelGGL(snappy_hip::compress_blocks_oracle_kernel, dim3(waves), dim3(64), 0, st, w, block_size, slot_stride,
-                           g_oracle_records, counter);
+        const uint32_t waves = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nb, shape.wave_slots()), (uint64_t)env_int("SNAPPY_HIP_GT_WAVES", (int)(20 * shape.cus)));
+        if (costs)
+            hipLaunchKernelGGL(snappy_hip::compress_blocks_oracle_kernel<true>, dim3(waves), dim3(64), 0, st, w, block_size, slot_stride,
+                               g_oracle_records, g_oracle_prevw, memo, counter);
+        else
+            hipLaunchKernelGGL(snappy_hip::compress_blocks_oracle_kernel<false>, dim3(waves), dim3(64), 0, st, w, block_size, slot_stride,
+                               g_oracle_records, g_oracle_prevw, memo, counter);
         HIP_TRY(hipGetLastError());
         return SNAPPY_HIP_OK;
     }

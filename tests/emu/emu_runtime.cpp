@@ -300,7 +300,7 @@ uint64_t emu_compress_oracle(const uint8_t* in, uint64_t n, uint32_t block_size,
     w.slots[0] = slots.data();
     w.block_bytes[0] = bytes.data();
     uint32_t counter = 0;
-    emu::launch(nb < 3 ? nb : 3, 64, [&] { snappy_hip::compress_blocks_oracle_kernel(w, block_size, stride, rec, &counter); });
+    emu::launch(nb < 3 ? nb : 3, 64, [&] { snappy_hip::compress_blocks_oracle_kernel<false>(w, block_size, stride, rec, nullptr, nullptr, &counter); });
     emu::launch(1, 1024, [&] {
         snappy_hip::scan_block_bytes_kernel(bytes.data(), nb, (uint32_t)n, block_size, stream, offsets.data(), &stream_len);
     });

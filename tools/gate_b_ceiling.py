@@ -53,10 +53,18 @@ def main():
     host_lib().gate_b_records(host.ctypes.data, n, bs, rec.ctypes.data)
     print(f"host records for {mib} MiB: {time.time() - t0:.1f} s", flush=True)
     d_rec = torch.from_numpy(rec).cuda()
+    prevw = np.zeros(n + 64, dtype=np.uint16)
+    HL = host_lib()
+    HL.gate_b_prevw.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p]
+    HL.gate_b_prevw(host.ctypes.data, n, bs, prevw.ctypes.data)
+    d_prevw = torch.from_numpy(prevw).cuda()
     L = shb.lib()
     L.snappy_hip_debug_set_oracle_records.argtypes = [ctypes.c_void_p]
     L.snappy_hip_debug_set_oracle_records.restype = None
     L.snappy_hip_debug_set_oracle_records(d_rec.data_ptr())
+    L.snappy_hip_debug_set_oracle_prevw.argtypes = [ctypes.c_void_p]
+    L.snappy_hip_debug_set_oracle_prevw.restype = None
+    L.snappy_hip_debug_set_oracle_prevw(d_prevw.data_ptr())
 
     ws = shb.CompressWorkspace(n, bs)
     d_stream = torch.empty(ws.stream_capacity(n) + 16, dtype=torch.uint8, device="cuda")
@@ -66,6 +74,8 @@ def main():
                ("LDS-table kernel alone, 4 per CU", "SNAPPY_HIP_K1_STREAM=3,SNAPPY_HIP_COMPRESS_VARIANT=1")]
     for per_cu in (8, 12, 16, 20, 24, 28, 32):
         configs.append((f"FREE TABLE (oracle records), {per_cu} wavefronts per CU", f"SNAPPY_HIP_COMPRESS_VARIANT=6,SNAPPY_HIP_GT_WAVES={per_cu * 256}"))
+    for per_cu in (16, 20, 24):
+        configs.append((f"FREE ANSWERS, PAID LOOK-UPS (bitmap + memo array), {per_cu} wavefronts per CU", f"SNAPPY_HIP_COMPRESS_VARIANT=7,SNAPPY_HIP_GT_WAVES={per_cu * 256}"))
     if len(sys.argv) > 2 and sys.argv[2] == "pmc":      # under rocprofv3 --pmc: the cached global-table kernel and the free-table kernel only
         configs = [configs[1]] + [c for c in configs if "24 wavefronts" in c[0]]
     ref = None

@@ -61,6 +61,37 @@ static void one_block(const uint8_t* blk, uint32_t n, uint32_t* rec, uint16_t* t
     }
 }
 
+// prevw[p] = nearest earlier position of p's block with the same hash that lies BEFORE p's 64-aligned window, 0 if none
+// (what a parse-independent pass 1 would deliver; position 0 is never inserted, so 0 can stand for "none")
+static void one_block_prevw(const uint8_t* blk, uint32_t n, uint16_t* prevw, uint16_t* last)
+{
+    uint32_t ts = 256; while (ts < 16384 && ts < n) ts <<= 1;
+    int lg = 0; while ((1u << (lg + 1)) <= ts) lg++;
+    const int shift = 32 - lg;
+    memset(last, 0, 2 * ts);
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t end = (base + 64 < n) ? base + 64 : n;
+        for (uint32_t p = base; p < end; p++) prevw[p] = (p + 4 <= n) ? last[HASH(p)] : 0;
+        for (uint32_t p = base ? base : 1; p < end; p++) if (p + 4 <= n) last[HASH(p)] = (uint16_t)p;
+    }
+}
+
+void gate_b_prevw(const uint8_t* in, uint64_t len, uint32_t block_size, uint16_t* prevw)
+{
+    const int64_t nb = (int64_t)((len + block_size - 1) / block_size);
+#pragma omp parallel
+    {
+        uint16_t* last = (uint16_t*)malloc(2 * 16384);
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t b = 0; b < nb; b++) {
+            const uint64_t start = (uint64_t)b * block_size;
+            const uint32_t n = (uint32_t)((len - start < block_size) ? len - start : block_size);
+            one_block_prevw(in + start, n, prevw + start, last);
+        }
+        free(last);
+    }
+}
+
 void gate_b_records(const uint8_t* in, uint64_t len, uint32_t block_size, uint32_t* rec)
 {
     const int64_t nb = (int64_t)((len + block_size - 1) / block_size);
