@@ -608,6 +608,8 @@ def main():
                          "traffic_source": "profiles/pmc_traffic.json (offline rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of each K1 "
                                            "form alone, bytes per input byte) x this run's block share of the two forms",
                          "lds_table_block_share": round(share, 4),
+                         # what the kernel IS bound by (offline counter passes, like `traffic`): instruction issue, not HBM bytes
+                         "issue": (pmc or {}).get("k1_issue"),
                          "algorithmic_bytes_per_launch": int(algo_bytes), "avg_launch_ms": round(c_ms, 4),
                          "decompress_kernel": {"achieved": round(d_algo / (d_ms * 1e-3) / 1e9, 3),
                                                "frac": round(d_algo / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
