@@ -345,7 +345,7 @@ __device__ __forceinline__ void stream_store(const Table& table, const StreamWin
 }
 
 // What the stream form hands to "the other half" of a window's work -- the duplicate analysis in front of the parse and the
-// emission behind it.  One wavefront per block: both are done in place.  (snappy_k1_duo.hpp: a second wavefront does them.)
+// emission behind it.  One wavefront per block: both are done in place.  (The Mate parameter is the seam round 3's duo form used -- a second wavefront doing both: profiles/HISTORY.md -- and round 4's free-table experiment uses: csrc/ablation/k1_oracle_table.hpp.)
 __device__ __forceinline__ void stream_emit(uint8_t* __restrict__ dst, const uint8_t* __restrict__ blk, uint32_t& op, uint32_t& next_emit,
                                             uint32_t base, uint32_t x0, uint32_t ent, uint32_t extv, unsigned long long H,
                                             unsigned long long COV, bool by_copy, uint32_t r_out, bool long_copy, uint32_t ip,

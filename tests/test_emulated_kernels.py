@@ -177,8 +177,8 @@ sys.path.insert(0, sys.argv[1])
 import datagen, emu_lib as emu, oracle_lib as oracle
 from conftest import golden_bytes
 text = golden_bytes("plrabn12.txt")
-cases = [golden_bytes("terror2.txt")[:60000], datagen.text_random_interleave(text, 60000), datagen.periodic(40000, 7), datagen.records(60000),
-         datagen.zeros(20000)]
+cases = [golden_bytes("terror2.txt")[:40000], datagen.text_random_interleave(text, 40000), datagen.periodic(20000, 7), datagen.records(40000),
+         datagen.zeros(9000)]
 for data in cases:
     for bs in (32768, 65535):
         ref = oracle.compress(data, bs)
@@ -188,7 +188,7 @@ print("ok")
 """
 
 
-@pytest.mark.parametrize("seed", [1, 5])
+@pytest.mark.parametrize("seed", [5])
 def test_emulated_slot_cache_under_shuffled_lane_schedules(seed):
     """The slot cache's store protocol (CachedGlobalTable::store_masked) lets the lanes of one call race for a cache word and
     reads back who won.  EMU_SHUFFLE runs the emulator's fibers -- the lanes -- in random order between two collectives, so
