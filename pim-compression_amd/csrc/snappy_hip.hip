@@ -271,6 +271,11 @@ launch_shape::DeviceShape device_shape()
             shapes[dev].lds_per_cu = (uint32_t)p.maxSharedMemoryPerMultiProcessor;
             shapes[dev].wave_slots_per_cu = (uint32_t)p.maxThreadsPerMultiProcessor / 64u;
         }
+        // SNAPPY_HIP_TEST_DEVICE_CUS (test hook, read once per device): pretend the device has this many compute units -- a
+        // partition of the chip as CPX / NPS modes make it -- so that the launch and scratch sizing for a small device can be
+        // exercised on a whole one (tests/test_gpu_parity.py)
+        const int fake = env_int("SNAPPY_HIP_TEST_DEVICE_CUS", 0);
+        if (fake > 0 && (uint32_t)fake <= shapes[dev].cus) shapes[dev].cus = (uint32_t)fake;
         known[dev] = true;
     }
     return shapes[dev];

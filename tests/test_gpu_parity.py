@@ -593,6 +593,40 @@ def test_block_with_three_lanes_in_one_slot_cache_word(shb, monkeypatch):
         assert gpu_compress(shb, data, 32768) == ref, stream_form
 
 
+def test_launches_sized_for_a_partition_of_the_chip():
+    """The launches and the hash-table scratch are sized from the device's properties (csrc/launch_shape.hpp).  With
+    SNAPPY_HIP_TEST_DEVICE_CUS=32 the library believes it runs on a 32-CU partition (CPX mode): the scratch it asks for is an
+    eighth, its grids are an eighth, and the bytes are the oracle's -- in a process of its own, because the shape is read once
+    per device."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, os.path.join(sys.argv[1], "pim-compression_amd")); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch
+import oracle_lib as oracle, snappy_hip_binding as shb, datagen
+from conftest import golden_bytes
+assert shb.lib().snappy_hip_compress_scratch_bytes() == 256 + 32 * 32 * 65536, shb.lib().snappy_hip_compress_scratch_bytes()
+prose = datagen.dickens_like([golden_bytes(n + ".txt") for n in ("plrabn12", "world192", "terror2", "alice")])
+data = (prose * 7)[:2000 * 32768 + 777]                      # 2,001 blocks: more than the 1,024 wavefront slots of 32 CUs
+ref = oracle.compress(data, 32768, threads=8)
+t = torch.zeros(len(data) + 16, dtype=torch.uint8, device="cuda")
+t[:len(data)] = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+for env in ({}, {"SNAPPY_HIP_HYBRID_MIN_BLOCKS": "1"}, {"SNAPPY_HIP_LDS_WAVES": "0"}, {"SNAPPY_HIP_COMPRESS_VARIANT": "1"}):
+    os.environ.update(env)
+    got = bytes(shb.compress_resident(t, 32768, n=len(data)).cpu().numpy())
+    assert got == ref, env
+    for k in env: os.environ.pop(k)
+st, out = shb.decompress_resident(torch.from_numpy(np.frombuffer(ref, dtype=np.uint8).copy()).cuda())
+assert st == 0 and bytes(out.cpu().numpy()) == data
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SNAPPY_HIP_TEST_DEVICE_CUS="32")
+    r = subprocess.run([sys.executable, "-c", code, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
+
+
 def test_product_library_refuses_ablation_only_knob_values(shb, monkeypatch):
     """SNAPPY_HIP_GT_CACHE=256 / 1024 and SNAPPY_HIP_K1_STREAM bit 2 exist in the ablation build only; the product library
     must fail loudly instead of running its default under that label (ADVICE r03)."""
