@@ -229,8 +229,8 @@ class Batch:
         there), and the containers go through in `groups` launches so that the decode of group g (second stream) runs
         underneath the compression of group g+1.  The host reads the index check results once, at the end.
         stream_alone: the decoder gets nothing from the compressor but the framed streams -- the block index comes from the
-        serial walk of each stream's size chain (ONE index_streams launch over the group's streams) instead of the
-        compressor's offsets checked link by link."""
+        streams' own size chains (ONE snappy_hip_index_streams call over the group's streams: parallel segments, the serial
+        walk for what they leave) instead of the compressor's offsets checked link by link."""
         shb, torch = self.shb, self.torch
         if not self.count:
             return
@@ -321,11 +321,22 @@ class Batch:
         ms = [a.elapsed_time(b) for a, b in self.kernel_events[key]]
         return (sum(ms) / len(ms)) if ms else None
 
-    def walk_ms(self):
-        """The serial size-chain walk (index_streams_kernel) of container 0, timed outside the step for the record."""
+    def walk_ms(self, serial=False):
+        """snappy_hip_index_streams on container 0's stream, timed outside the step for the record: the size chain resolved in
+        parallel segments (default), or -- serial=True, SNAPPY_HIP_INDEX_PARALLEL=0 -- by the serial walk alone."""
         torch, shb = self.torch, self.shb
         if not self.count:
             return None
+        if serial:
+            prev = os.environ.get("SNAPPY_HIP_INDEX_PARALLEL")
+            os.environ["SNAPPY_HIP_INDEX_PARALLEL"] = "0"
+            try:
+                return self.walk_ms()
+            finally:
+                if prev is None:
+                    os.environ.pop("SNAPPY_HIP_INDEX_PARALLEL", None)
+                else:
+                    os.environ["SNAPPY_HIP_INDEX_PARALLEL"] = prev
         boff = torch.empty(self.nb[0] + 1, dtype=torch.int64, device="cuda")
         res = torch.zeros(2, dtype=torch.int32, device="cuda")
         d = shb.make_stream_descs([dict(stream=self.streams[0], stream_len=self.stream_lens[0], block_offsets=boff, result=res,
@@ -522,7 +533,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ok = ok and batch.verify_last_step()
-    # ---- the same K steps with a decoder that starts from the streams alone (its own timed region, reported beside `value`) ----
+    # ---- the same K steps with a decoder that starts from the streams alone (its own timed region, reported beside `value`):
+    #      the block index comes from snappy_hip_index_streams inside the step ----
     elapsed_alone = None
     if not args.no_stream_alone:
         batch.step(stream_alone=True)
@@ -596,10 +608,13 @@ def main():
             "value_from_stream_alone": round(tot_bytes / secs_alone / 1e9, 4) if secs_alone else None,
             "ms_per_step_from_stream_alone": round(secs_alone / args.steps * 1e3, 3) if secs_alone else None,
             "index": {"mode": "value: the compressor's offsets verified against the size chain, every link in parallel "
-                              "(snappy_hip_verify_index); value_from_stream_alone: the chain walked on the device, all streams "
-                              "of the rank in one launch (snappy_hip_index_streams)",
+                              "(snappy_hip_verify_index); value_from_stream_alone: the chain found on the device from the "
+                              "stream's bytes alone, all streams of the rank in one call (snappy_hip_index_streams: 256 "
+                              "walkers per stream over segments of the chain, laid end to end iff every segment ends exactly "
+                              "on the next one's start; the serial walk for any stream that leaves unresolved)",
                       "fallback_serial_walks": batch.fallback_walks,
-                      "serial_walk_ms_container0": round(batch.walk_ms(), 3)},
+                      "index_ms_container0": round(batch.walk_ms(), 3),
+                      "serial_walk_ms_container0": round(batch.walk_ms(serial=True), 3)},
             "roofline": {"bound": "hbm", "kernel": "K1 = compress_blocks_global_table_kernel + compress_blocks_lds_table_kernel "
                                                    "(co-running pair, one launch over the rank's containers)",
                          "achieved": round(achieved, 3),

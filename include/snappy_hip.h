@@ -200,8 +200,17 @@ SNAPPY_HIP_API int snappy_hip_compact(const uint8_t *d_slots, uint32_t slot_stri
                        uint8_t *d_stream, uint64_t *d_offsets, uint64_t *d_stream_len, void *stream);
 
 /*
- * Walk the u32 size chains of `count` streams (one wavefront each), the device form of the
- * host pre-scan snappy_decompress.c:317-340.  d_descs: device array of `count` descriptors.
+ * Find the u32 size chains of `count` streams from the streams' bytes alone, the device form of the
+ * host pre-scan snappy_decompress.c:317-340.  d_descs: device array of `count` descriptors; for every stream
+ * block_offsets[0 .. num_blocks) and result[0] (SNAPPY_HIP_BLOCK_OK / _INVALID), result[1] (blocks found) are written.
+ * The chain is first sought in parallel: 256 walkers per stream start at recognised block boundaries and walk their
+ * share; the shares are laid end to end iff each one ends exactly on the next one's starting point and the hops number
+ * num_blocks -- which makes them the chain, whatever the recognition did.  A stream this leaves unresolved (blocks of a
+ * few bytes, a damaged stream, a stream of 4 GiB or more) is walked serially, one wavefront per stream, with the same
+ * result.  SNAPPY_HIP_INDEX_PARALLEL=0: the serial walk only.
+ * Uses a library-owned device workspace (2.1 MB per stream of the call), allocated on first use and when a call brings
+ * more streams than any before it on this device: that is the only case in which this function calls the allocator (and
+ * waits for the previous call on that device); otherwise it only enqueues.
  */
 SNAPPY_HIP_API int snappy_hip_index_streams(const snappy_hip_stream_desc *d_descs, uint32_t count, void *stream);
 

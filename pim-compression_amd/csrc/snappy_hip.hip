@@ -398,6 +398,29 @@ void launch_global_table_kernel(uint32_t grid, hipStream_t st, const snappy_hip:
 
 }  // namespace
 
+namespace {
+
+// Workspace of the parallel-segment chain resolution (csrc/snappy_kernels.hpp: chain_*_kernel), one per device, owned by the
+// library: 2.1 MB per stream of a call, allocated on first use and when a call brings more streams than any before it (the
+// only moment snappy_hip_index_streams touches the allocator).  Calls that overlap in time on different streams are ordered
+// by an event: the later one waits ON THE DEVICE for the earlier one to be done with the workspace.
+struct ChainWorkspace {
+    std::mutex m;
+    uint32_t* mem = nullptr;
+    uint32_t streams = 0;
+    hipEvent_t last_use = nullptr;
+};
+ChainWorkspace* chain_workspace(int dev)
+{
+    static ChainWorkspace* per_device[64] = {};
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (!per_device[dev]) per_device[dev] = new ChainWorkspace;    // never destroyed (threads may outlive statics)
+    return per_device[dev];
+}
+
+}  // namespace
+
 // ===========================================================================
 // resident API
 // ===========================================================================
@@ -680,11 +703,48 @@ int snappy_hip_index_streams(const snappy_hip_stream_desc* d_descs, uint32_t cou
     static_assert(sizeof(snappy_hip_stream_desc) == sizeof(snappy_hip::StreamDesc), "descriptor layout");
     if (count == 0) return SNAPPY_HIP_OK;
     if (!d_descs) return fail(SNAPPY_HIP_ERR_ARG, "null descriptor array");
+    hipStream_t st = (hipStream_t)stream;
+    const snappy_hip::StreamDesc* dd = reinterpret_cast<const snappy_hip::StreamDesc*>(d_descs);
     // SNAPPY_HIP_INDEX_READERS=0: the walking wavefront alone, without the read-ahead workgroups on its XCD
     const uint32_t group = env_int("SNAPPY_HIP_INDEX_READERS", 1) ? snappy_hip::kIndexGroup : 1u;
-    hipLaunchKernelGGL(snappy_hip::index_streams_kernel, dim3(count * group), dim3(64 * snappy_hip::kIndexWgWaves), 0,
-                       (hipStream_t)stream, reinterpret_cast<const snappy_hip::StreamDesc*>(d_descs), count, group);
-    HIP_TRY(hipGetLastError());
+    // SNAPPY_HIP_INDEX_PARALLEL=0: the serial walk only (the parallel segments resolve a stream or leave it to that walk)
+    if (!env_int("SNAPPY_HIP_INDEX_PARALLEL", 1)) {
+        hipLaunchKernelGGL(snappy_hip::index_streams_kernel, dim3(count * group), dim3(64 * snappy_hip::kIndexWgWaves), 0, st, dd, count,
+                           group, (const uint32_t*)nullptr);
+        HIP_TRY(hipGetLastError());
+        return SNAPPY_HIP_OK;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(SNAPPY_HIP_ERR_ARG, "device index out of range");
+    ChainWorkspace* cw = chain_workspace(dev);
+    std::lock_guard<std::mutex> lock(cw->m);
+    constexpr size_t kSegs = snappy_hip::kChainSegments, kCap = snappy_hip::kChainSegCap;
+    const size_t words_per_stream = kSegs * (3 + kCap) + 1;
+    if (cw->streams < count) {
+        if (cw->last_use) HIP_TRY(hipEventSynchronize(cw->last_use));
+        if (cw->mem) (void)hipFree(cw->mem);
+        cw->mem = nullptr;
+        cw->streams = 0;
+        HIP_TRY(hipMalloc((void**)&cw->mem, (size_t)count * words_per_stream * sizeof(uint32_t)));
+        cw->streams = count;
+    }
+    if (!cw->last_use) HIP_TRY(hipEventCreateWithFlags(&cw->last_use, hipEventDisableTiming));
+    HIP_TRY(hipStreamWaitEvent(st, cw->last_use, 0));             // (an event never recorded counts as complete)
+    snappy_hip::ChainWork w;
+    w.anchor = cw->mem;
+    w.seg_hops = w.anchor + (size_t)count * kSegs;
+    w.seg_ok = w.seg_hops + (size_t)count * kSegs;
+    w.hops = w.seg_ok + (size_t)count * kSegs;
+    w.resolved = w.hops + (size_t)count * kSegs * kCap;
+    hipLaunchKernelGGL(snappy_hip::chain_anchor_kernel, dim3(count * (uint32_t)kSegs), dim3(64), 0, st, dd, count, w);
+    hipLaunchKernelGGL(snappy_hip::chain_walk_kernel, dim3(count * (uint32_t)kSegs), dim3(64), 0, st, dd, count, w);
+    hipLaunchKernelGGL(snappy_hip::chain_finish_kernel, dim3(count), dim3(1024), 0, st, dd, count, w);
+    hipLaunchKernelGGL(snappy_hip::index_streams_kernel, dim3(count * group), dim3(64 * snappy_hip::kIndexWgWaves), 0, st, dd, count, group,
+                       (const uint32_t*)w.resolved);
+    const hipError_t launched = hipGetLastError();
+    HIP_TRY(hipEventRecord(cw->last_use, st));
+    HIP_TRY(launched);
     return SNAPPY_HIP_OK;
 }
 

@@ -344,6 +344,31 @@ int emu_decompress_variant(const uint8_t* stream, uint64_t stream_len, uint32_t 
     return 0;
 }
 
+// The size chain in parallel segments (chain_anchor / chain_walk / chain_finish kernels) followed by the serial walk for
+// what they leave unresolved, as snappy_hip_index_streams enqueues them.  offsets: num_blocks entries; result[0..1] as the
+// kernels leave it; returns 1 if the parallel segments resolved the stream, 0 if the serial walk had to.
+int emu_index_parallel(const uint8_t* stream, uint64_t stream_len, uint64_t* offsets, uint32_t total_len, uint32_t block_size,
+                       uint32_t header_len, uint32_t* result)
+{
+    const uint32_t nb = block_size ? (uint32_t)(((uint64_t)total_len + block_size - 1) / block_size) : 0;
+    result[0] = result[1] = 7;
+    snappy_hip::StreamDesc d{stream, stream_len, offsets, result, total_len, block_size, header_len, nb};
+    constexpr size_t K = snappy_hip::kChainSegments, C = snappy_hip::kChainSegCap;
+    std::vector<uint32_t> mem(K * (3 + C) + 1, 0xdeadbeefu);
+    snappy_hip::ChainWork w;
+    w.anchor = mem.data();
+    w.seg_hops = w.anchor + K;
+    w.seg_ok = w.seg_hops + K;
+    w.hops = w.seg_ok + K;
+    w.resolved = w.hops + K * C;
+    emu::launch((uint32_t)K, 64, [&] { snappy_hip::chain_anchor_kernel(&d, 1, w); });
+    emu::launch((uint32_t)K, 64, [&] { snappy_hip::chain_walk_kernel(&d, 1, w); });
+    emu::launch(1, 1024, [&] { snappy_hip::chain_finish_kernel(&d, 1, w); });
+    const int resolved = (int)w.resolved[0];
+    emu::launch(1, 64, [&] { snappy_hip::index_streams_kernel(&d, 1, 1u, w.resolved); });
+    return resolved;
+}
+
 // Runs verify_index_begin_kernel + verify_index_kernel on a candidate index of num_blocks + 1 offsets.
 void emu_verify_index(const uint8_t* stream, uint64_t stream_len, uint64_t* offsets, uint32_t total_len, uint32_t block_size,
                       uint32_t header_len, uint32_t* result)

@@ -44,6 +44,9 @@ def lib():
         L.emu_verify_index.restype = None
         L.emu_verify_index.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                        ctypes.c_uint32, ctypes.c_void_p]
+        L.emu_index_parallel.restype = ctypes.c_int
+        L.emu_index_parallel.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                         ctypes.c_uint32, ctypes.c_void_p]
         _LIB = L
     return _LIB
 
@@ -74,3 +77,13 @@ def verify_index(stream, offsets, total_len, block_size, header_len):
     res = np.zeros(2, dtype=np.uint32)
     lib().emu_verify_index(a.ctypes.data, a.size, offs.ctypes.data, total_len, block_size, header_len, res.ctypes.data)
     return int(res[0]), int(res[1])
+
+
+def index_parallel(stream, total_len, block_size, header_len):
+    """chain_*_kernel + the serial walk for what they leave -> (resolved in parallel?, status, blocks, offsets)."""
+    a = np.frombuffer(stream, dtype=np.uint8).copy()
+    nb = (total_len + block_size - 1) // block_size if block_size else 0
+    offs = np.zeros(max(nb, 1), dtype=np.uint64)
+    res = np.zeros(2, dtype=np.uint32)
+    resolved = lib().emu_index_parallel(a.ctypes.data, a.size, offs.ctypes.data, total_len, block_size, header_len, res.ctypes.data)
+    return bool(resolved), int(res[0]), int(res[1]), offs[:nb].copy()

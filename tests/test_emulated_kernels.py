@@ -213,3 +213,66 @@ def test_emulated_slot_cache_block_with_three_lanes_in_one_cache_word():
     ref = oracle.compress(data, 32768)
     for cv in (43503, 42503, 53503):
         assert emu.compress(data, 32768, variant=cv) == ref, cv
+
+
+def _chain(stream):
+    """(total_len, block_size, header_len, offsets of the chain) by the plain walk of snappy_decompress.c:317-340."""
+    total, bs, hdr = oracle.read_header(stream)
+    nb = (total + bs - 1) // bs
+    offs, at = [], hdr
+    for _ in range(nb):
+        offs.append(at)
+        at += 4 + int.from_bytes(stream[at:at + 4], "little")
+    assert at == len(stream)
+    return total, bs, hdr, offs
+
+
+def test_emulated_size_chain_in_parallel_segments():
+    """snappy_hip_index_streams' parallel form (chain_anchor / chain_walk / chain_finish kernels, csrc/snappy_kernels.hpp):
+    walkers start at recognised block boundaries and their segments are laid end to end iff every one ends exactly on the next
+    one's start.  Whatever the walkers make of the bytes, the result must be the chain of snappy_decompress.c:317-340 -- from
+    the segments when they fit, from the serial walk when they do not (tiny blocks overflow a segment's buffer; literal
+    payloads full of zero bytes look like size fields)."""
+    text = golden_bytes("plrabn12.txt")
+    big = datagen.text_random_interleave(text, 1_500_000) + datagen.records(700_000) + datagen.zeros(300_000) + datagen.random_bytes(600_000)
+    sparse = bytes(2_000_000)                                   # all zero: the stream is copies of zeros
+    zero_literals = b"".join(bytes([i & 0xff, 0, 0, 0, 0, 0, (i >> 3) & 0xff, 0]) for i in range(150_000))
+    parallel = serial = 0
+    for data, sizes in ((big, (32768, 65535, 4096, 700)), (golden_bytes("world192.txt"), (32768, 64, 16)), (sparse, (32768,)),
+                        (zero_literals, (32768, 8192)), (golden_bytes("alice.txt"), (32768,))):
+        for bs in sizes:
+            stream = oracle.compress(data, bs)
+            total, got_bs, hdr, ref = _chain(stream)
+            resolved, st, nb, offs = emu.index_parallel(stream, total, got_bs, hdr)
+            assert st == 0 and nb == len(ref) and offs.tolist() == ref, (len(data), bs, resolved)
+            parallel += resolved
+            serial += not resolved
+    assert parallel >= 8                                        # the segments do resolve the ordinary cases themselves
+    assert serial >= 1                                          # 16-byte blocks: ~6,500 hops per segment do not fit its 2,048
+
+
+def test_emulated_size_chain_segments_on_damaged_streams():
+    """Truncated, extended and corrupted streams: the parallel segments must not resolve what is not a chain, must stay inside
+    the stream, and the serial walk behind them reports the stream as the reference's pre-scan would (invalid)."""
+    data = datagen.text_random_interleave(golden_bytes("plrabn12.txt"), 1_200_000)
+    stream = oracle.compress(data, 32768)
+    total, bs, hdr, ref = _chain(stream)
+    # cut inside a block / right behind a size field / one byte short
+    for cut in (len(stream) - 1, ref[-1] + 4, ref[len(ref) // 2] + 100, ref[3] + 2):
+        resolved, st, nb, _ = emu.index_parallel(stream[:cut], total, bs, hdr)
+        assert not resolved and st != 0, cut
+    # bytes appended: the last hop no longer ends on the stream's end
+    resolved, st, nb, _ = emu.index_parallel(stream + b"\x00" * 7, total, bs, hdr)
+    assert not resolved and st != 0
+    # a size field made one larger / made huge / zeroed, in the first, a middle and the last block
+    for b in (0, len(ref) // 2, len(ref) - 1):
+        for new in (lambda v: v + 1, lambda v: 0xfffffff0, lambda v: 0):
+            bad = bytearray(stream)
+            v = int.from_bytes(bad[ref[b]:ref[b] + 4], "little")
+            bad[ref[b]:ref[b] + 4] = (new(v) & 0xffffffff).to_bytes(4, "little")
+            resolved, st, nb, _ = emu.index_parallel(bytes(bad), total, bs, hdr)
+            assert not resolved and st != 0, (b, v)
+    # a header that promises one block more or fewer than the chain has
+    for wrong_total in (total + 32768, total - 32768):
+        resolved, st, nb, _ = emu.index_parallel(stream, wrong_total, bs, hdr)
+        assert not resolved and st != 0

@@ -329,6 +329,55 @@ def test_batched_index_matches_scan_offsets(shb):
         assert int(ws.block_bytes[:nb].sum().item()) + int(ws.offsets[0].item()) == slen
 
 
+def test_index_streams_parallel_segments_agree_with_the_serial_walk(shb, monkeypatch):
+    """snappy_hip_index_streams resolves the size chain in parallel segments and leaves to the serial walk what they cannot
+    resolve.  Both ways must give the chain -- on a 300 MB stream (256 segments), with 16-byte blocks (segment
+    buffers overflow: serial walk), on a short stream (one segment), on literal payloads full of zero bytes -- and both must
+    call a truncated or corrupted stream invalid.  SNAPPY_HIP_INDEX_PARALLEL=0 is the serial walk alone."""
+    import torch
+    prose = datagen.dickens_like(_prose())
+    zero_literals = b"".join(bytes([i & 0xff, 0, 0, 0, 0, 0, (i >> 3) & 0xff, 0]) for i in range(300_000))
+    cases = [((prose * 30)[:300_000_000], 32768), (prose[:3_000_000], 16), (golden_bytes("terror2.txt"), 32768), (zero_literals, 32768),
+             (datagen.random_bytes(5_000_000), 65535)]
+    entries, keep = [], []
+    for data, bs in cases:
+        stream = oracle.compress(data, bs, threads=8)
+        total, got_bs, hdr = oracle.read_header(stream)
+        nb = shb.num_blocks(total, got_bs)
+        offs, at = [], hdr
+        for _ in range(nb):
+            offs.append(at)
+            at += 4 + int.from_bytes(stream[at:at + 4], "little")
+        d_stream = to_dev(stream)
+        for damage in (None, "truncate", "size"):
+            slen, d = len(stream), d_stream
+            if damage == "truncate":
+                slen = offs[nb // 2] + 3
+            elif damage == "size":
+                bad = bytearray(stream)
+                bad[offs[nb // 2]] ^= 0x10
+                d = to_dev(bytes(bad))
+            boff = torch.zeros(nb, dtype=torch.int64, device="cuda")
+            res = torch.full((2,), 7, dtype=torch.int32, device="cuda")
+            entries.append(dict(stream=d, stream_len=slen, block_offsets=boff, result=res, total_len=total, block_size=got_bs,
+                                header_len=hdr, num_blocks=nb))
+            keep.append((damage, offs, boff, res, nb))
+    for parallel in ("1", "0"):
+        monkeypatch.setenv("SNAPPY_HIP_INDEX_PARALLEL", parallel)
+        for _, _, boff, res, _ in keep:
+            boff.zero_()
+            res.fill_(7)
+        for lo in range(0, len(entries), 8):                     # (8 streams per call, as bench.py's step)
+            shb.index_streams(shb.make_stream_descs(entries[lo:lo + 8]), len(entries[lo:lo + 8]))
+        torch.cuda.synchronize()
+        for damage, offs, boff, res, nb in keep:
+            st, found = res.cpu().tolist()
+            if damage is None:
+                assert (st, found) == (0, nb) and boff.cpu().tolist() == offs, (parallel, nb)
+            else:
+                assert st != 0, (parallel, damage, nb)
+
+
 def test_seeded_fuzz_vs_oracle(shb):
     r = np.random.default_rng(2026)
     for seed in range(48):
