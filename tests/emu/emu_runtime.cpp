@@ -1,6 +1,7 @@
 // Fiber-based lockstep wave emulator + C entry points that drive the real kernel source on the CPU.
 // Test infrastructure only (see tests/emu/hip/hip_runtime.h).
 #include <hip/hip_runtime.h>   // resolves to tests/emu/hip/hip_runtime.h via -I
+#include <sys/mman.h>
 #include <ucontext.h>
 
 #include <cstdio>
@@ -209,6 +210,25 @@ void launch(uint32_t grid, uint32_t block, const std::function<void()>& body)
 
 }  // namespace emu
 
+// A copy of `n` bytes that ends exactly at an inaccessible page: a read of even one byte beyond the stream faults here
+// instead of passing unnoticed (the kernels that take streams from outside must stay inside them whatever the bytes say).
+struct GuardedCopy {
+    uint8_t* base = nullptr;
+    size_t mapped = 0;
+    uint8_t* p = nullptr;
+    GuardedCopy(const uint8_t* src, size_t n)
+    {
+        const size_t page = 4096;
+        mapped = ((n + page - 1) / page + 1) * page;
+        base = (uint8_t*)mmap(nullptr, mapped, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (base == MAP_FAILED) abort();
+        if (mprotect(base + mapped - page, page, PROT_NONE) != 0) abort();
+        p = base + mapped - page - n;
+        if (n) memcpy(p, src, n);
+    }
+    ~GuardedCopy() { munmap(base, mapped); }
+};
+
 // ---------------------------------------------------------------------------
 // C entry points used by tests/test_emulated_kernels.py
 // ---------------------------------------------------------------------------
@@ -315,9 +335,11 @@ uint64_t emu_compress(const uint8_t* in, uint64_t n, uint32_t block_size, uint8_
 
 // Runs index_streams_kernel + decompress_blocks_kernel on the emulator.
 // Returns 0 on success, 1 if any block (or the chain) is invalid.
-int emu_decompress_variant(const uint8_t* stream, uint64_t stream_len, uint32_t total_len, uint32_t block_size,
+int emu_decompress_variant(const uint8_t* stream_in, uint64_t stream_len, uint32_t total_len, uint32_t block_size,
                            uint32_t header_len, uint8_t* out, int variant)
 {
+    GuardedCopy guarded(stream_in, stream_len);                  // K2 and the walk must not read one byte beyond the stream
+    const uint8_t* stream = guarded.p;
     const uint32_t nb = block_size ? (uint32_t)(((uint64_t)total_len + block_size - 1) / block_size) : 0;
     if (nb == 0) return stream_len == header_len ? 0 : 1;
     std::vector<uint64_t> boff(nb, 0);
@@ -347,11 +369,13 @@ int emu_decompress_variant(const uint8_t* stream, uint64_t stream_len, uint32_t 
 // The size chain in parallel segments (chain_anchor / chain_walk / chain_finish kernels) followed by the serial walk for
 // what they leave unresolved, as snappy_hip_index_streams enqueues them.  offsets: num_blocks entries; result[0..1] as the
 // kernels leave it; returns 1 if the parallel segments resolved the stream, 0 if the serial walk had to.
-int emu_index_parallel(const uint8_t* stream, uint64_t stream_len, uint64_t* offsets, uint32_t total_len, uint32_t block_size,
+int emu_index_parallel(const uint8_t* stream_in, uint64_t stream_len, uint64_t* offsets, uint32_t total_len, uint32_t block_size,
                        uint32_t header_len, uint32_t* result)
 {
     const uint32_t nb = block_size ? (uint32_t)(((uint64_t)total_len + block_size - 1) / block_size) : 0;
     result[0] = result[1] = 7;
+    GuardedCopy guarded(stream_in, stream_len);
+    const uint8_t* stream = guarded.p;
     snappy_hip::StreamDesc d{stream, stream_len, offsets, result, total_len, block_size, header_len, nb};
     constexpr size_t K = snappy_hip::kChainSegments, C = snappy_hip::kChainSegCap;
     std::vector<uint32_t> mem(K * (3 + C) + 1, 0xdeadbeefu);

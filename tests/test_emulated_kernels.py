@@ -276,3 +276,43 @@ def test_emulated_size_chain_segments_on_damaged_streams():
     for wrong_total in (total + 32768, total - 32768):
         resolved, st, nb, _ = emu.index_parallel(stream, wrong_total, bs, hdr)
         assert not resolved and st != 0
+
+
+def test_emulated_size_chain_segments_on_arbitrary_bytes():
+    """Property: for ANY bytes, header fields and block count, the parallel segments + serial walk give what the plain walk of
+    snappy_decompress.c:317-340 gives (the chain, or invalid) -- and read nothing beyond the stream: the emulator places the
+    stream right in front of an inaccessible page.  Seeded: random bytes, valid streams with random spans overwritten, streams
+    cut at random places, sparse bytes (mostly zero: plausible size fields everywhere)."""
+    import random
+    rnd = random.Random(20261005)
+    base = oracle.compress(datagen.text_random_interleave(golden_bytes("plrabn12.txt"), 700_000) + bytes(200_000), 8192)
+    total, bs, hdr, ref = _chain(base)
+
+    def plain_walk(stream, hdr, nb):
+        at = hdr
+        for _ in range(nb):
+            if at + 4 > len(stream):
+                return None
+            at += 4 + int.from_bytes(stream[at:at + 4], "little")
+        return at == len(stream)
+
+    for case in range(60):
+        kind = case % 4
+        if kind == 0:
+            stream = bytes(rnd.getrandbits(8) for _ in range(rnd.randrange(1, 40_000)))
+        elif kind == 1:
+            b = bytearray(base)
+            for _ in range(rnd.randrange(1, 4)):
+                lo = rnd.randrange(0, len(b) - 64)
+                b[lo:lo + rnd.randrange(1, 64)] = bytes(rnd.getrandbits(8) for _ in range(8))[:1] * 1
+            stream = bytes(b)
+        elif kind == 2:
+            stream = base[:rnd.randrange(0, len(base))]
+        else:
+            stream = bytes(rnd.getrandbits(8) if rnd.random() < 0.03 else 0 for _ in range(rnd.randrange(1, 300_000)))
+        h = hdr if kind in (1, 2) else rnd.randrange(0, 12)
+        nb = len(ref) if kind in (1, 2) else rnd.randrange(0, 50)
+        t = total if kind in (1, 2) else nb * 8192
+        resolved, st, found, _ = emu.index_parallel(stream, t, 8192, h)
+        want = plain_walk(stream, h, nb) if len(stream) >= h else None
+        assert (st == 0) == bool(want), (case, kind, len(stream), h, nb, resolved, st, found)
