@@ -142,10 +142,10 @@ sys.path.insert(0, sys.argv[1])
 import datagen, emu_lib as emu, oracle_lib as oracle
 from conftest import golden_bytes
 text = golden_bytes("plrabn12.txt")
-big = [golden_bytes("terror2.txt")[:50000], datagen.text_random_interleave(text, 40000), datagen.records(40000), datagen.low_entropy(20000),
-       datagen.lz_structured(40000, 7), b"abcd" + bytes(40000)]
-small = [datagen.zeros(9000), datagen.periodic(9000, 5)] + [d[:8000] for _, d in datagen.edge_cases(text)]
-for data, sizes in [(d, (32768, 4097)) for d in big] + [(d, (32768, 65535, 700)) for d in small]:
+big = [golden_bytes("terror2.txt")[:36000], datagen.text_random_interleave(text, 34000), datagen.records(34000), datagen.low_entropy(20000),
+       datagen.lz_structured(34000, 7), b"abcd" + bytes(34000)]
+small = [datagen.zeros(9000), datagen.periodic(9000, 5)] + [d[:6000] for _, d in datagen.edge_cases(text)]
+for data, sizes in [(d, (32768, 4097)) for d in big] + [(d, (65535, 700)) for d in small]:
     for bs in sizes:
         ref = oracle.compress(data, bs)
         for cv in (3501, 43503):
