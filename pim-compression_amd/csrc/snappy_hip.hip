@@ -23,6 +23,7 @@
 #include "../../include/snappy_hip.h"
 #include "shard_devices.hpp"
 #include "launch_shape.hpp"
+#include "host_chain.hpp"
 #include "snappy_kernels.hpp"
 
 namespace {
@@ -1648,20 +1649,28 @@ static snappy_status decompress_gpu_body(struct host_buffer_context* input, stru
         runtime->pre += now_seconds() - t0;
         return decompress_pipelined(buf, in_total, output, runtime, one, 1, devs, bs, total, chunk_blocks);
     }
-    // host pre-scan of the size chain (:306-341)
-    std::vector<uint64_t> off(nb + 1);
-    for (uint64_t i = 0; i < nb; ++i) {
-        if (at + 4 > in_total) {
-            fprintf(stderr, "snappy_hip: truncated stream (block %lu of %lu)\n", (unsigned long)i, (unsigned long)nb);
+    // host pre-scan of the size chain (:306-341): the blocks are split over the devices before anything is copied, so every
+    // offset is needed first.  In parallel shares where the stream is long enough (csrc/host_chain.hpp: exact by
+    // construction, ~7 ms per GiB of serial pointer chase otherwise -- the whole of `pre`, and it does not shrink with the
+    // number of devices); SNAPPY_HIP_HOST_WALK_THREADS=1 is the serial walk alone, which also names a damaged stream's fault.
+    std::vector<uint64_t> off;
+    const unsigned walk_threads = (unsigned)std::max(1, env_int("SNAPPY_HIP_HOST_WALK_THREADS",
+                                                               (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
+    if (!host_chain::parallel_walk(buf, in_total, at, nb, bs, walk_threads, off)) {
+        off.assign(nb + 1, 0);
+        for (uint64_t i = 0; i < nb; ++i) {
+            if (at + 4 > in_total) {
+                fprintf(stderr, "snappy_hip: truncated stream (block %lu of %lu)\n", (unsigned long)i, (unsigned long)nb);
+                return SNAPPY_INVALID_INPUT;
+            }
+            off[i] = at;
+            at += 4 + (uint64_t)le32_host(buf + at);
+        }
+        off[nb] = at;
+        if (at != in_total) {
+            fprintf(stderr, "snappy_hip: size chain ends at %lu, stream has %lu bytes\n", (unsigned long)at, (unsigned long)in_total);
             return SNAPPY_INVALID_INPUT;
         }
-        off[i] = at;
-        at += 4 + (uint64_t)le32_host(buf + at);
-    }
-    off[nb] = at;
-    if (at != in_total) {
-        fprintf(stderr, "snappy_hip: size chain ends at %lu, stream has %lu bytes\n", (unsigned long)at, (unsigned long)in_total);
-        return SNAPPY_INVALID_INPUT;
     }
     const uint64_t per = (nb + gpus - 1) / gpus;
     std::vector<DecompressShard> sh(gpus);
