@@ -605,6 +605,8 @@ def test_lds_form_block_count_is_written_by_every_launch_shape(shb, monkeypatch)
     (share 1.0); the global-table kernel alone has share 0; the mix lies in between; and a small launch after a large one must
     not read back the large one's count."""
     import torch
+    if os.environ.get("SNAPPY_HIP_TEST_DEVICE_CUS"):
+        pytest.skip("the expectations below are those of a whole MI355X (312 blocks <= 4 x 256 LDS-table wavefronts)")
     prose = datagen.dickens_like(_prose())                        # 312 blocks: the small-input rule applies
     big = (prose * 17)[:5000 * 32768]                              # 5000 blocks: the concurrent launch
     ws = shb.CompressWorkspace(len(big), 32768)
