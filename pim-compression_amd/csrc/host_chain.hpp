@@ -15,6 +15,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -63,37 +64,38 @@ inline uint64_t find_anchor(const uint8_t* buf, uint64_t len, uint64_t first, ui
 
 // off[0 .. num_blocks] (the last entry = len) if the shares fit together; false: walk serially.
 // threads <= 1, or a stream too short to share out, returns false at once.
+// min_share: bytes of stream a thread must have to be worth starting (~50 us; the serial walk does ~8 ms per GiB)
 inline bool parallel_walk(const uint8_t* buf, uint64_t len, uint64_t first, uint64_t num_blocks, uint32_t block_size, unsigned threads,
-                          std::vector<uint64_t>& off)
+                          std::vector<uint64_t>& off, uint64_t min_share = 16u << 20)
 {
-    constexpr uint64_t kMinShare = 4u << 20;                      // below ~4 MiB per thread the serial walk is as quick
-    if (len <= first || num_blocks == 0) return false;
+    if (len <= first || num_blocks == 0 || min_share == 0) return false;
     const uint64_t body = len - first;
-    uint64_t shares = body / kMinShare;
+    uint64_t shares = body / min_share;
     if (shares > threads) shares = threads;
     if (shares < 2) return false;
     const uint32_t maxc = max_block(block_size);
+    // one thread per share: find the share's starting point, publish it, then walk to the next published starting point
+    // (a share waits only for the shares behind it to have LOOKED, not walked)
     std::vector<uint64_t> anchor(shares, kNone);
-    anchor[0] = first;
-    {
-        std::vector<std::thread> th;
-        for (uint64_t k = 1; k < shares; ++k)
-            th.emplace_back([&, k] { anchor[k] = find_anchor(buf, len, first, maxc, first + body * k / shares, first + body * (k + 1) / shares); });
-        for (auto& t : th) t.join();
-    }
+    std::vector<std::atomic<int>> looked(shares);
+    for (auto& l : looked) l.store(0, std::memory_order_relaxed);
     std::vector<std::vector<uint64_t>> hops(shares);
     std::vector<char> ok(shares, 1);
     {
         std::vector<std::thread> th;
         for (uint64_t k = 0; k < shares; ++k)
             th.emplace_back([&, k] {
+                anchor[k] = k == 0 ? first : find_anchor(buf, len, first, maxc, first + body * k / shares, first + body * (k + 1) / shares);
+                looked[k].store(1, std::memory_order_release);
                 if (anchor[k] == kNone) return;                   // no walker: the one before it walks through this share
                 uint64_t next = len;
-                for (uint64_t j = k + 1; j < shares; ++j)
+                for (uint64_t j = k + 1; j < shares; ++j) {
+                    while (!looked[j].load(std::memory_order_acquire)) std::this_thread::yield();
                     if (anchor[j] != kNone) {
                         next = anchor[j];
                         break;
                     }
+                }
                 std::vector<uint64_t>& h = hops[k];
                 h.reserve((size_t)(num_blocks / shares + 64));
                 uint64_t at = anchor[k];

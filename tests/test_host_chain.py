@@ -18,7 +18,7 @@ DRIVER = r'''
 #include <cstdlib>
 #include <sys/mman.h>
 #include "host_chain.hpp"
-// usage: driver <file> <first> <num_blocks> <block_size> <threads>  ->  "declined" | "ok <fnv of the offsets>" ; exit 3 on a wrong chain
+// usage: driver <file> <first> <num_blocks> <block_size> <threads> <min share bytes>  ->  "declined" | "ok <fnv of the offsets>" ; exit 3 on a wrong chain
 int main(int argc, char** argv) {
     FILE* f = fopen(argv[1], "rb"); if (!f) return 2;
     fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
     const uint64_t first = strtoull(argv[2], 0, 10), nb = strtoull(argv[3], 0, 10);
     const uint32_t bs = (uint32_t)strtoul(argv[4], 0, 10);
     std::vector<uint64_t> off;
-    if (!host_chain::parallel_walk(buf, (uint64_t)n, first, nb, bs, (unsigned)atoi(argv[5]), off)) { puts("declined"); return 0; }
+    if (!host_chain::parallel_walk(buf, (uint64_t)n, first, nb, bs, (unsigned)atoi(argv[5]), off, strtoull(argv[6], 0, 10))) { puts("declined"); return 0; }
     // whatever it accepted must be the plain walk
     uint64_t at = first;
     for (uint64_t i = 0; i < nb; ++i) {
@@ -54,10 +54,11 @@ def _build(tmp_path):
     return str(exe)
 
 
-def _run(exe, tmp_path, stream, first, nb, bs, threads=8):
+def _run(exe, tmp_path, stream, first, nb, bs, threads=8, min_share=1 << 20):
+    """(shares of 1 MiB here, so that streams of a few MB exercise the machinery; the library's default is 16 MiB)"""
     p = tmp_path / "s.bin"
     p.write_bytes(stream)
-    r = subprocess.run([exe, str(p), str(first), str(nb), str(bs), str(threads)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(p), str(first), str(nb), str(bs), str(threads), str(min_share)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stderr[-500:])
     return r.stdout.strip()
 
@@ -92,6 +93,9 @@ def test_host_parallel_size_chain(tmp_path):
     small = oracle.compress(golden_bytes("world192.txt"), 32768)
     total, bs, hdr = oracle.read_header(small)
     assert _run(exe, tmp_path, small, hdr, (total + bs - 1) // bs, bs) == "declined"
+    stream = oracle.compress(data[:20_000_000], 32768, threads=8)    # ~9 MB of stream: below two shares of the default 16 MiB
+    total, bs, hdr = oracle.read_header(stream)
+    assert _run(exe, tmp_path, stream, hdr, (total + bs - 1) // bs, bs, min_share=16 << 20) == "declined"
     # arbitrary bytes: whatever comes back is never a wrong chain (the driver exits 3 on one)
     rnd = np.random.default_rng(7)
     for k in range(6):
