@@ -43,9 +43,11 @@ constexpr uint64_t kNone = ~0ull;
 // the first recognised boundary in [lo, hi), kNone if there is none
 inline uint64_t find_anchor(const uint8_t* buf, uint64_t len, uint64_t first, uint32_t maxc, uint64_t lo, uint64_t hi)
 {
-    for (uint64_t a = lo; a < hi; ++a) {
+    unsigned tries = 0;                                           // bounded work whatever the bytes are
+    for (uint64_t a = lo; a < hi && tries < 64; ++a) {
         uint64_t at = a, nx = 0;
         if (!plausible(buf, len, first, maxc, a, &nx)) continue;
+        ++tries;
         bool good = true;
         at = nx;
         for (int hop = 0; hop < 4 && good && at != len; ++hop) {

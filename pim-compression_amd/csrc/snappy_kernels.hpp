@@ -1476,6 +1476,7 @@ constexpr uint32_t kChainSegments = 256;            // walkers per stream
 constexpr uint32_t kChainSegCap = 2048;             // hops a walker can record (segments of ~2 MB hold ~130 blocks of 32 KiB)
 constexpr uint32_t kChainMinSegBytes = 1u << 17;    // shorter streams use fewer walkers
 constexpr uint32_t kChainNone = 0xffffffffu;
+constexpr uint32_t kChainTries = 64;                // candidates a walker examines before it gives up its share
 struct ChainWork {                                  // device workspace of one index_streams call: [stream][segment]
     uint32_t* anchor;                               // where the segment's walker starts (kChainNone: no walker)
     uint32_t* seg_hops;                             // hops it recorded
@@ -1529,11 +1530,15 @@ __global__ __launch_bounds__(64) void chain_anchor_kernel(const StreamDesc* __re
         } else if (k < segs) {
             const uint64_t body = len - d.header_len;
             const uint64_t lo = d.header_len + body * k / segs, hi = d.header_len + body * (k + 1) / segs;
-            for (uint64_t pos = lo; pos < hi && found == kChainNone; pos += kWave) {
+            // (bounded work whatever the bytes are: a share whose first kChainTries candidates all fail gets no walker --
+            // the walker before it carries on through this share, or the stream goes to the serial walk)
+            uint32_t tries = 0;
+            for (uint64_t pos = lo; pos < hi && found == kChainNone && tries < kChainTries; pos += kWave) {
                 unsigned long long m = __ballot(pos + lane < hi && chain_plausible(d.stream, len, d.header_len, maxc, pos + lane));
-                while (m && found == kChainNone) {
+                while (m && found == kChainNone && tries < kChainTries) {
                     const uint64_t a = pos + (uint32_t)__builtin_ctzll(m);
                     m &= m - 1;
+                    ++tries;
                     // forward: the chain from `a` keeps landing on plausible starts (or reaches the end)
                     uint64_t at = a, nx = 0;
                     bool good = true;
