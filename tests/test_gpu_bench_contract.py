@@ -80,3 +80,17 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
                           "--warmup", "0", "--no-cpu-baseline"], cwd=ROOT, env=dict(env, SNAPPY_HIP_GT_CACHE="256"),
                          capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_rccl_path_with_one_rank():
+    """The N > 1 runs of the driver use RCCL (backend "nccl") for the barrier and the MAX / SUM reductions.  One rank is all
+    this box can give it, but the calls are the same: process group with a device id, barrier on the device, all_reduce of
+    device tensors (SNAPPY_BENCH_FORCE_DIST=1)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    d = _run([sys.executable, "bench.py", "--containers", "2", "--container-mib", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+             env={"SNAPPY_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                  "MASTER_PORT": str(port)})
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roundtrip_bit_exact"] is True
